@@ -1,0 +1,198 @@
+/*
+ * mbpe.h -- C-ABI of the MI355X-native BPE trainer hot path.
+ *
+ * Drop-in boundary for justinhj/minbpe-cc's lexical-tie-break training path.
+ * The reference has no FFI layer of its own; every entry point
+ * below names the reference code it replaces (paths relative to the
+ * reference checkout, code/include/...).  INTEGRATION.md shows the binding a
+ * reference maintainer would add inside Tokenizer::train.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross the boundary
+ *   - every function returns 0 (MBPE_OK) or a negative mbpe_status; the text
+ *     of the last error of the calling thread is mbpe_last_error()
+ *   - the caller owns every buffer it passes; the context owns device memory
+ *   - one context per GPU and per thread (thread-compatible, like the
+ *     reference's Tokenizer, which is not thread-safe: Tokenizer.h:67-72)
+ *   - there is NO CPU fallback: without a usable HIP device mbpe_create fails
+ *
+ * Token ids: the device stream holds 16-bit slots.  vocab_size may be at most
+ * MBPE_MAX_VOCAB_BASIC for a single-chunk corpus and MBPE_MAX_VOCAB_CHUNKED
+ * when chunk boundaries are present (one slot bit marks "last token of its
+ * chunk").  Larger requests return MBPE_ERR_VOCAB.
+ */
+#ifndef MBPE_H
+#define MBPE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBPE_API __attribute__((visibility("default")))
+
+#define MBPE_MAX_VOCAB_BASIC   65534u
+#define MBPE_MAX_VOCAB_CHUNKED 32766u
+
+typedef enum {
+    MBPE_OK            =  0,
+    MBPE_ERR_ARG       = -1,  /* bad argument (NULL, vocab_size < 256: Tokenizer.h:492) */
+    MBPE_ERR_NO_DEVICE = -2,  /* no HIP device / extension unusable */
+    MBPE_ERR_HIP       = -3,  /* a HIP runtime call failed */
+    MBPE_ERR_VOCAB     = -4,  /* vocab_size beyond the 16-bit slot format */
+    MBPE_ERR_STATE     = -5,  /* call order violated (e.g. steps before begin) */
+    MBPE_ERR_OOM       = -6,  /* device or host allocation failed */
+    MBPE_ERR_REGEX     = -7,  /* PCRE2 unavailable, compile or match error */
+    MBPE_ERR_SPLIT_GAP = -8,  /* split pattern left bytes unmatched */
+    MBPE_ERR_COMM      = -9,  /* RCCL unavailable or a collective failed */
+    MBPE_ERR_OVERFLOW  = -10, /* pair table or count overflow detected on device */
+    MBPE_ERR_IO        = -11  /* file could not be read / written */
+} mbpe_status;
+
+typedef struct mbpe_ctx mbpe_ctx;
+
+/* Per-run statistics; all times are milliseconds of device time measured
+ * with HIP events on the context's stream. */
+typedef struct {
+    uint64_t n_bytes;          /* corpus bytes loaded */
+    uint64_t n_chunks;         /* chunks after dropping NUL-quirk chunks */
+    uint64_t n_slots;          /* physical stream slots right now */
+    uint64_t n_live;           /* live tokens right now */
+    uint32_t n_merges;         /* merges performed so far */
+    uint32_t n_compactions;    /* stream compactions performed */
+    uint64_t n_pairs;          /* pairs ever inserted (== PairCount::get_count) */
+    float    ms_pair_count;    /* last pair-count scan kernel */
+    float    ms_begin;         /* widen + table build + first argmax */
+    float    ms_steps;         /* all merge steps so far */
+    uint32_t pair_count_launches;
+    uint32_t reserved;
+} mbpe_stats;
+
+MBPE_API const char *mbpe_last_error(void);
+MBPE_API const char *mbpe_version(void);
+
+/* ---- context ------------------------------------------------------- */
+
+/* Creates a context on HIP device `device_id`.  Fails with
+ * MBPE_ERR_NO_DEVICE when there is no such device. */
+MBPE_API int  mbpe_create(int device_id, mbpe_ctx **out);
+MBPE_API void mbpe_destroy(mbpe_ctx *ctx);
+
+/* ---- corpus -------------------------------------------------------- */
+
+/* Hands the training text to the device.  Replaces text_to_vector +
+ * create_lists (Tokenizer.h:85-100, :114-124): the corpus stays a byte
+ * array in HBM instead of one heap node per token.
+ *   text         n_bytes bytes; host memory, or device memory when
+ *                text_on_device != 0 (then it is used in place and must
+ *                stay valid until mbpe_train_begin returns)
+ *   chunk_off    n_chunks+1 ascending byte offsets, chunk c =
+ *                [chunk_off[c], chunk_off[c+1]); chunk_off[0] == 0 and
+ *                chunk_off[n_chunks] == n_bytes.  NULL = one chunk = the
+ *                whole text (Tokenizer.h:541-544).  Always host memory.
+ * Pairs are only counted and merged inside a chunk (Tokenizer.h:135-144,
+ * :311-319).  A chunk that starts with NUL and whose remainder parses with
+ * std::stoi collapses to one token in the reference (Tokenizer.h:86-93) and
+ * therefore never contributes a pair: such chunks are dropped here. */
+MBPE_API int mbpe_load_corpus(mbpe_ctx *ctx, const uint8_t *text, uint64_t n_bytes,
+                              const uint64_t *chunk_off, uint64_t n_chunks,
+                              int text_on_device);
+
+/* The pair-count scan on the loaded byte corpus: calculate_freqs
+ * (Tokenizer.h:127-146) with PairCountLexicalOrder::create_or_modify_pair
+ * (PairCount.h:249-260) as one histogram kernel.  table65536_out (host,
+ * optional) receives count[(first << 8) | second].  Test / bench
+ * granularity; mbpe_train_begin runs the same kernel. */
+MBPE_API int mbpe_pair_count_u8(mbpe_ctx *ctx, uint32_t *table65536_out);
+
+/* ---- training ------------------------------------------------------ */
+
+/* Prepares the training loop for `vocab_size` (>= 256, Tokenizer.h:492):
+ * pair-count scan, 16-bit slot stream, pair table, first argmax.
+ * Corresponds to Tokenizer.h:551-556. */
+MBPE_API int mbpe_train_begin(mbpe_ctx *ctx, uint32_t vocab_size);
+
+/* Runs up to n_steps iterations of the loop body Tokenizer.h:557-589:
+ * get_top_pair_count (PairCount.h:262-269), merge_chunks ->
+ * merge_incremental (Tokenizer.h:309-320, :202-306).  Stops early when the
+ * target vocab size is reached or the pair table is empty (:586-588).
+ * steps_done_out (optional) receives the number of merges made by this
+ * call. */
+MBPE_API int mbpe_train_steps(mbpe_ctx *ctx, uint32_t n_steps, uint32_t *steps_done_out);
+
+/* Copies the merges made so far: merges_out[2k], merges_out[2k+1] is the
+ * pair that became token 256+k (Tokenizer.h:578); counts_out[k] (optional)
+ * is its count when chosen (the verbose line, Tokenizer.h:566-576).
+ * cap_merges = capacity of the arrays in merges. */
+MBPE_API int mbpe_train_result(mbpe_ctx *ctx, uint32_t *merges_out, int32_t *counts_out,
+                               uint32_t cap_merges, uint32_t *n_merges_out);
+
+/* One call = Tokenizer::train's hot path (Tokenizer.h:551-589) for
+ * CONFLICT_RESOLUTION::LEXICAL: load + begin + all steps + result.
+ * merges_out must hold 2*(vocab_size-256) u32. */
+MBPE_API int mbpe_train_lexical(mbpe_ctx *ctx, const uint8_t *text, uint64_t n_bytes,
+                                const uint64_t *chunk_off, uint64_t n_chunks,
+                                uint32_t vocab_size,
+                                uint32_t *merges_out, int32_t *counts_out,
+                                uint32_t *n_merges_out, mbpe_stats *stats_out);
+
+MBPE_API int mbpe_get_stats(mbpe_ctx *ctx, mbpe_stats *out);
+
+/* ---- introspection (parity tests) ----------------------------------- */
+
+/* Live tokens of the stream in order (holes removed).  tokens_out may be
+ * NULL to query the length.  chunk_end_out (optional, same length) is 1
+ * where a token is the last of its chunk. */
+MBPE_API int mbpe_get_stream(mbpe_ctx *ctx, uint32_t *tokens_out, uint8_t *chunk_end_out,
+                             uint64_t cap, uint64_t *n_out);
+
+/* All pairs ever inserted with their current counts
+ * (PairCount::get_all, PairCount.h:271-278; order unspecified).
+ * Arrays may be NULL to query the size. */
+MBPE_API int mbpe_get_pairs(mbpe_ctx *ctx, uint32_t *first_out, uint32_t *second_out,
+                            int32_t *count_out, uint64_t cap, uint64_t *n_out);
+
+/* Forces a stream compaction now (normally triggered by the hole ratio). */
+MBPE_API int mbpe_compact(mbpe_ctx *ctx);
+
+/* Tuning knobs (tests force rare paths with them).
+ *   "compact_den"   compact when holes * den >= slots (default 8; 0 = never)
+ *   "batch"         merges per host round trip (default 64)
+ *   "use_graph"     1 = replay merges from a captured hipGraph (default 1)
+ */
+MBPE_API int mbpe_set_option(mbpe_ctx *ctx, const char *name, int64_t value);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---------------- */
+
+/* Rank 0 creates the id, every rank receives it out of band (the launcher
+ * broadcasts it, e.g. over torch.distributed) and calls mbpe_comm_init.
+ * After that mbpe_load_corpus takes the rank's contiguous shard of the
+ * corpus (whole chunks for chunked corpora; any byte range of a one-chunk
+ * corpus) and training all-reduces the per-merge count deltas and boundary
+ * descriptors so every rank takes identical decisions. */
+#define MBPE_COMM_ID_BYTES 128
+MBPE_API int mbpe_comm_unique_id(uint8_t id_out[MBPE_COMM_ID_BYTES]);
+MBPE_API int mbpe_comm_init(mbpe_ctx *ctx, const uint8_t id[MBPE_COMM_ID_BYTES],
+                            int rank, int n_ranks);
+
+/* ---- host-side pieces of the reference path ------------------------- */
+
+/* Regex pre-split, Tokenizer.h:500-540: successive non-empty PCRE2 matches
+ * (options PCRE2_UTF|PCRE2_UCP, +PCRE2_CASELESS when the pattern contains
+ * "(?i:", :407-415; PCRE2_NO_UTF_CHECK at match time, :512) become chunks.
+ * Returns a handle holding n_chunks+1 offsets. */
+typedef struct mbpe_split mbpe_split;
+MBPE_API int  mbpe_presplit(const char *pattern, const uint8_t *text, uint64_t n_bytes,
+                            mbpe_split **out);
+MBPE_API uint64_t        mbpe_split_count(const mbpe_split *s);
+MBPE_API const uint64_t *mbpe_split_offsets(const mbpe_split *s);
+MBPE_API void            mbpe_split_free(mbpe_split *s);
+
+/* The split patterns of Tokenizer.h:59-60 ("gpt2", "gpt4"; "basic" = ""). */
+MBPE_API const char *mbpe_split_pattern(const char *encoder_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBPE_H */

@@ -1,0 +1,19 @@
+// Thread-local last-error text behind mbpe_last_error() (include/mbpe.h).
+#include "mbpe.h"
+#include "mbpe_host.h"
+
+#include <string>
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+namespace mbpe_host {
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+const char *last_error() { return g_last_error.c_str(); }
+}  // namespace mbpe_host
+
+extern "C" {
+const char *mbpe_last_error(void) { return mbpe_host::last_error(); }
+const char *mbpe_version(void) { return "mbpe-amd 0.1 (gfx950)"; }
+}

@@ -1,0 +1,205 @@
+// Regex pre-split on the host: the part of Tokenizer::train that feeds the hot
+// path (reference code/include/Tokenizer.h:500-540, compile options :407-415,
+// JIT :435, match flags :512).  PCRE2 is bound at run time with dlopen because
+// the image ships libpcre2-8.so.0 without its development header; the few
+// entry points used are declared by hand below.
+#include "mbpe.h"
+#include "mbpe_host.h"
+
+#include <dlfcn.h>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+// --- the slice of the PCRE2 8-bit API this file uses ----------------------
+constexpr uint32_t kPCRE2_CASELESS     = 0x00000008u;
+constexpr uint32_t kPCRE2_UCP          = 0x00020000u;
+constexpr uint32_t kPCRE2_UTF          = 0x00080000u;
+constexpr uint32_t kPCRE2_NO_UTF_CHECK = 0x40000000u;
+constexpr uint32_t kPCRE2_JIT_COMPLETE = 0x00000001u;
+constexpr int      kPCRE2_ERROR_NOMATCH = -1;
+
+struct Pcre2Api {
+    void *lib = nullptr;
+    void *(*compile)(const uint8_t *, size_t, uint32_t, int *, size_t *, void *) = nullptr;
+    void (*code_free)(void *) = nullptr;
+    int (*jit_compile)(void *, uint32_t) = nullptr;
+    void *(*match_data_create_from_pattern)(const void *, void *) = nullptr;
+    void (*match_data_free)(void *) = nullptr;
+    int (*match)(const void *, const uint8_t *, size_t, size_t, uint32_t, void *, void *) = nullptr;
+    size_t *(*get_ovector_pointer)(void *) = nullptr;
+    int (*get_error_message)(int, uint8_t *, size_t) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+Pcre2Api &pcre2() {
+    static Pcre2Api api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"libpcre2-8.so.0", "libpcre2-8.so"};
+        for (const char *n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) { api.why = "libpcre2-8.so.0 not found (needed for gpt2/gpt4 encoders)"; return; }
+        auto sym = [&](const char *s) { return dlsym(api.lib, s); };
+#define MBPE_BIND(field, name) \
+        api.field = reinterpret_cast<decltype(api.field)>(sym(name)); \
+        if (!api.field) { api.why = std::string("missing PCRE2 symbol ") + name; return; }
+        MBPE_BIND(compile, "pcre2_compile_8")
+        MBPE_BIND(code_free, "pcre2_code_free_8")
+        MBPE_BIND(jit_compile, "pcre2_jit_compile_8")
+        MBPE_BIND(match_data_create_from_pattern, "pcre2_match_data_create_from_pattern_8")
+        MBPE_BIND(match_data_free, "pcre2_match_data_free_8")
+        MBPE_BIND(match, "pcre2_match_8")
+        MBPE_BIND(get_ovector_pointer, "pcre2_get_ovector_pointer_8")
+        MBPE_BIND(get_error_message, "pcre2_get_error_message_8")
+#undef MBPE_BIND
+        api.ok = true;
+    });
+    return api;
+}
+
+std::string pcre2_message(int code) {
+    uint8_t buf[256] = {0};
+    pcre2().get_error_message(code, buf, sizeof(buf));
+    return std::string(reinterpret_cast<char *>(buf));
+}
+
+}  // namespace
+
+namespace mbpe_host {
+
+Splitter::~Splitter() {
+    if (match_data_) pcre2().match_data_free(match_data_);
+    if (code_) pcre2().code_free(code_);
+}
+
+// Tokenizer(const string &pattern), Tokenizer.h:391-451.
+int Splitter::compile(const std::string &pattern, std::string *err) {
+    pattern_ = pattern;
+    if (pattern.empty()) return MBPE_OK;   // "basic": no split, Tokenizer.h:400
+    Pcre2Api &p = pcre2();
+    if (!p.ok) { *err = p.why; return MBPE_ERR_REGEX; }
+    uint32_t options = kPCRE2_UTF | kPCRE2_UCP;                          // :407
+    if (pattern.find("(?i:") != std::string::npos) options |= kPCRE2_CASELESS;  // :413-415
+    int errorcode = 0;
+    size_t erroroffset = 0;
+    code_ = p.compile(reinterpret_cast<const uint8_t *>(pattern.data()), pattern.size(), options,
+                      &errorcode, &erroroffset, nullptr);
+    if (!code_) {
+        *err = "PCRE2 pattern compilation failed: " + pcre2_message(errorcode);   // :427-431
+        return MBPE_ERR_REGEX;
+    }
+    p.jit_compile(code_, kPCRE2_JIT_COMPLETE);   // failure is not fatal, :435-442
+    match_data_ = p.match_data_create_from_pattern(code_, nullptr);
+    if (!match_data_) { *err = "PCRE2 match data creation failed."; return MBPE_ERR_REGEX; }
+    return MBPE_OK;
+}
+
+// The match loop of Tokenizer::train / encode, Tokenizer.h:506-540 and :676-703:
+// every non-empty match [start,end) is a chunk; an empty match advances the
+// offset by one byte; NOMATCH ends the loop.
+int Splitter::split(const uint8_t *text, uint64_t n, std::vector<uint64_t> *starts,
+                    std::vector<uint64_t> *ends, std::string *err) const {
+    starts->clear();
+    ends->clear();
+    if (!code_) {                 // no pattern: one chunk, :541-544
+        starts->push_back(0);
+        ends->push_back(n);
+        return MBPE_OK;
+    }
+    Pcre2Api &p = pcre2();
+    size_t offset = 0;
+    for (;;) {
+        int rc = p.match(code_, text, n, offset, kPCRE2_NO_UTF_CHECK, match_data_, nullptr);
+        if (rc < 0) {
+            if (rc == kPCRE2_ERROR_NOMATCH) break;
+            *err = "PCRE2 match error: " + pcre2_message(rc);            // :517-522
+            return MBPE_ERR_REGEX;
+        }
+        size_t *ov = p.get_ovector_pointer(match_data_);
+        size_t start = ov[0], end = ov[1];
+        if (start == end) {                                              // :529-533
+            if (offset >= n) break;
+            offset++;
+            continue;
+        }
+        starts->push_back(start);
+        ends->push_back(end);
+        offset = end;
+    }
+    return MBPE_OK;
+}
+
+const char *split_pattern_for(const std::string &encoder) {
+    // Tokenizer.h:59-60
+    static const char *gpt2 =
+        "'(?:[sdmt]|ll|ve|re)| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
+    static const char *gpt4 =
+        "'(?i:[sdmt]|ll|ve|re)|[^\\r\\n\\p{L}\\p{N}]?+\\p{L}+|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]++[\\r\\n]*|\\s*[\\r\\n]|\\s+(?!\\S)|\\s+";
+    if (encoder == "gpt2") return gpt2;
+    if (encoder == "gpt4") return gpt4;
+    if (encoder == "basic") return "";
+    return nullptr;
+}
+
+}  // namespace mbpe_host
+
+// ---- C-ABI ---------------------------------------------------------------
+
+struct mbpe_split {
+    std::vector<uint64_t> off;   // n_chunks + 1
+};
+
+extern "C" {
+
+int mbpe_presplit(const char *pattern, const uint8_t *text, uint64_t n_bytes, mbpe_split **out) {
+    if (!pattern || (!text && n_bytes) || !out) {
+        mbpe_host::set_last_error("mbpe_presplit: NULL argument");
+        return MBPE_ERR_ARG;
+    }
+    std::string err;
+    mbpe_host::Splitter sp;
+    int rc = sp.compile(pattern, &err);
+    if (rc != MBPE_OK) { mbpe_host::set_last_error(err); return rc; }
+    std::vector<uint64_t> starts, ends;
+    rc = sp.split(text, n_bytes, &starts, &ends, &err);
+    if (rc != MBPE_OK) { mbpe_host::set_last_error(err); return rc; }
+    // The device layout wants contiguous chunks; the gpt2/gpt4 patterns match
+    // every byte of valid UTF-8 input, so a gap means an unsupported pattern.
+    uint64_t pos = 0;
+    for (size_t i = 0; i < starts.size(); i++) {
+        if (starts[i] != pos) {
+            mbpe_host::set_last_error("split pattern left bytes unmatched at offset " + std::to_string(pos));
+            return MBPE_ERR_SPLIT_GAP;
+        }
+        pos = ends[i];
+    }
+    if (pos != n_bytes) {
+        mbpe_host::set_last_error("split pattern left bytes unmatched at offset " + std::to_string(pos));
+        return MBPE_ERR_SPLIT_GAP;
+    }
+    mbpe_split *s = new mbpe_split();
+    s->off.reserve(starts.size() + 1);
+    for (uint64_t v : starts) s->off.push_back(v);
+    s->off.push_back(n_bytes);
+    if (starts.empty()) { s->off.clear(); s->off.push_back(0); }
+    *out = s;
+    return MBPE_OK;
+}
+
+uint64_t mbpe_split_count(const mbpe_split *s) { return s ? s->off.size() - 1 : 0; }
+const uint64_t *mbpe_split_offsets(const mbpe_split *s) { return s ? s->off.data() : nullptr; }
+void mbpe_split_free(mbpe_split *s) { delete s; }
+
+const char *mbpe_split_pattern(const char *encoder_name) {
+    if (!encoder_name) return nullptr;
+    return mbpe_host::split_pattern_for(encoder_name);
+}
+
+}  // extern "C"
