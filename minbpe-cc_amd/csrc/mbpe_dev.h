@@ -1,0 +1,134 @@
+// Device-side data layout shared by the HIP kernels (kernels.hip) and the
+// host orchestration (train.cpp).  See DESIGN.md "Data layout in HBM".
+#ifndef MBPE_DEV_H
+#define MBPE_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mbpe {
+
+// ---- token stream -----------------------------------------------------
+// The corpus is a stream of 16-bit SLOTS.  A slot is either a live token or
+// a HOLE left behind by a merge (the second token of a merged pair); holes
+// are squeezed out by an occasional compaction pass.  In a chunked corpus
+// bit 15 of a live slot marks "last token of its chunk" (no pair starts at
+// such a token: Tokenizer.h:135-144, :311-319).
+constexpr uint32_t kHole = 0xFFFFu;    // also "no token" in tile summaries
+constexpr uint32_t kEndBit = 0x8000u;  // chunked corpora only
+
+constexpr int kTile = 2048;            // slots per tile (one workgroup)
+constexpr int kMergeThreads = 256;
+constexpr int kSlotsPerThread = kTile / kMergeThreads;  // 8 = one 16-byte load
+
+// What a tile exposes to its neighbours; written by the pass that last
+// changed the tile, read (never the neighbour's slots) by the next pass, so
+// in-place rewriting cannot race with halo reads.
+struct __attribute__((aligned(16))) TileSum {
+    uint16_t head0, head1;   // first / second live token (kHole if absent)
+    uint16_t tail1, tail0;   // second-last / last live token
+    uint16_t n_live;         // live tokens in the tile
+    uint16_t tail_run;       // trailing live tokens equal (raw) to tail0
+    uint16_t pad0, pad1;
+};
+static_assert(sizeof(TileSum) == 16, "TileSum must be 16 bytes");
+
+// What a rank exposes to its neighbours in a multi-GPU run: the same
+// information for the whole shard (looked through empty tiles).
+struct RankEdge {
+    uint32_t head0, head1;   // first two live tokens of the shard
+    uint32_t tail1, tail0;   // last two live tokens of the shard
+    uint32_t n_live_lo, n_live_hi;
+    uint32_t tail_run_lo, tail_run_hi;  // trailing run of tail0 (raw)
+};
+
+// ---- pair table ---------------------------------------------------------
+// Open-addressing hash (key -> entry index) plus dense entry arrays that the
+// argmax kernel scans.  key = (first << 16) | second.  Entries are never
+// removed: PairCountLexicalOrder never erases (PairCount.h:249-260), so a
+// pair whose count returned to 0 is still a candidate (SURVEY.md 8-S rule 4).
+constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
+
+struct PairTable {
+    uint32_t *hkey;      // [hcap] kEmptyKey when free
+    uint32_t *hidx;      // [hcap] index into ekey/ecnt
+    uint32_t *ekey;      // [ecap]
+    int32_t  *ecnt;      // [ecap]
+    uint32_t  hmask;     // hcap - 1
+    uint32_t  ecap;
+};
+
+// Mutable scalars shared by the kernels of one context.
+struct DevCtl {
+    uint32_t n_entries;      // pairs ever inserted (== PairCount::get_count())
+    uint32_t err;            // sticky error bits, see kErr*
+    uint32_t m;              // matches of the current merge (this rank)
+    uint32_t adj;            // adjacent match pairs of the current merge
+    unsigned long long removed_total;  // holes created since the last compaction
+    unsigned long long n_live;         // live tokens in this rank's shard
+    unsigned long long scan_total;     // output of the tile scan (compaction)
+    uint32_t pad[6];
+};
+
+constexpr uint32_t kErrTableFull   = 1u;
+constexpr uint32_t kErrNegCount    = 2u;
+constexpr uint32_t kErrMissingPair = 4u;
+
+// packed argmax word: (count << 32) | ~key  -- larger is better:
+// count descending, then key ascending == (first, second) ascending,
+// i.e. CompareLexicalOrder, PairCount.h:194-207.
+__host__ __device__ inline unsigned long long pack_best(int32_t count, uint32_t key) {
+    return ((unsigned long long)(uint32_t)count << 32) | (uint32_t)(~key);
+}
+
+// ---- kernel launchers (implemented in kernels.hip) ------------------------
+struct Launch {
+    hipStream_t stream;
+};
+
+void launch_fill_u32(hipStream_t s, uint32_t *p, uint64_t n, uint32_t v);
+void launch_fill_u16(hipStream_t s, uint16_t *p, uint64_t n, uint16_t v);
+
+// pair-count scan over the byte corpus. endmask: bit i set = byte i is the
+// last byte of its chunk (NULL for a one-chunk corpus). bp[first<<8|second].
+void launch_pair_count_u8(hipStream_t s, const uint8_t *text, uint64_t n,
+                          const uint8_t *endmask, uint32_t *bp, int n_workgroups);
+
+// u8 corpus -> 16-bit slot stream (+END flags), padded to whole tiles with holes
+void launch_widen(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask,
+                  uint16_t *tok, uint64_t n_slots_padded);
+
+// recompute every tile summary from the slots
+void launch_summarize(hipStream_t s, const uint16_t *tok, TileSum *sums, uint32_t n_tiles,
+                      DevCtl *ctl, int set_n_live);
+
+// dense byte-pair histogram -> pair table
+void launch_table_init(hipStream_t s, const uint32_t *bp, PairTable t, DevCtl *ctl);
+// rebuild the hash index from the entry arrays (after growing the table)
+void launch_table_rehash(hipStream_t s, PairTable t, DevCtl *ctl);
+
+// best[0] = max over entries of pack_best(count, key)   (best must be zeroed)
+void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best);
+
+// one merge pass over the stream, in place
+void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sin, TileSum *sout,
+                  uint32_t n_tiles, const unsigned long long *best, uint32_t new_id,
+                  uint32_t endbit, uint32_t *L, uint32_t *R, DevCtl *ctl,
+                  const RankEdge *left_edge, const RankEdge *right_edge);
+
+// fold the merge's count deltas (L, R, m, adj) into the pair table
+void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best,
+                  uint32_t new_id, uint32_t *L, uint32_t *R, const uint32_t *gm_gadj);
+
+// compaction: exclusive scan of n_live over tiles, then scatter
+void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles,
+                      unsigned long long *offsets, DevCtl *ctl);
+void launch_compact_scatter(hipStream_t s, const uint16_t *src, const TileSum *sums,
+                            const unsigned long long *offsets, uint32_t n_tiles, uint16_t *dst);
+
+// this rank's RankEdge from its tile summaries
+void launch_rank_edge(hipStream_t s, const TileSum *sums, uint32_t n_tiles, RankEdge *out);
+
+}  // namespace mbpe
+
+#endif

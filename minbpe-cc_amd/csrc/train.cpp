@@ -1,0 +1,602 @@
+// Host orchestration of the BPE training hot path behind the C-ABI
+// (include/mbpe.h).  Drives the kernels of kernels.hip on one HIP stream:
+//
+//   begin : pair-count scan -> pair table, widen -> slot stream, first argmax
+//   step k: merge(best[k]) -> apply deltas -> argmax -> best[k+1]
+//
+// which is the loop of Tokenizer::train (reference Tokenizer.h:551-589) for
+// CONFLICT_RESOLUTION::LEXICAL.  The chosen pair never leaves the device
+// between steps (the merge kernel reads best[k] from HBM); the host only
+// synchronises once per batch of merges for housekeeping: error flags,
+// compaction of holes, growth of the pair table.
+#include "mbpe.h"
+#include "mbpe_dev.h"
+#include "../host/mbpe_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mbpe;
+
+namespace {
+
+std::string hip_err(const char *what, hipError_t e) {
+    return std::string(what) + ": " + hipGetErrorString(e);
+}
+
+#define HIPCHK(expr)                                                   \
+    do {                                                               \
+        hipError_t e__ = (expr);                                       \
+        if (e__ != hipSuccess) {                                       \
+            mbpe_host::set_last_error(hip_err(#expr, e__));            \
+            return e__ == hipErrorOutOfMemory ? MBPE_ERR_OOM : MBPE_ERR_HIP; \
+        }                                                              \
+    } while (0)
+
+uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+uint32_t next_pow2(uint64_t v) {
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return (uint32_t)p;
+}
+
+// std::stoi on the remainder of a NUL-led chunk (reference Tokenizer.h:86-93):
+// true when it parses, i.e. the chunk collapses to a single token.
+bool stoi_parses(const uint8_t *s, uint64_t n) {
+    uint64_t i = 0;
+    while (i < n && (s[i] == ' ' || (s[i] >= 9 && s[i] <= 13))) i++;
+    bool neg = false;
+    if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; i++; }
+    if (i >= n || s[i] < '0' || s[i] > '9') return false;
+    long long v = 0;
+    while (i < n && s[i] >= '0' && s[i] <= '9') {
+        v = v * 10 + (s[i] - '0');
+        if (v > 4294967296LL) return false;
+        i++;
+    }
+    if (neg) v = -v;
+    return v <= 2147483647LL && v >= -2147483648LL;
+}
+
+template <typename T>
+void dfree(T *&p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+}  // namespace
+
+struct mbpe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cus = 256;
+
+    // corpus
+    const uint8_t *d_text = nullptr;
+    uint8_t *d_text_owned = nullptr;
+    uint8_t *d_endmask = nullptr;
+    uint64_t n_bytes = 0;
+    uint64_t n_chunks = 0;
+    bool chunked = false;
+    bool loaded = false;
+    bool inert = false;          // whole corpus collapses to one token (NUL quirk, basic)
+
+    // slot stream
+    uint16_t *tok[2] = {nullptr, nullptr};
+    int cur = 0;
+    uint64_t cap_slots = 0;      // allocated slots per buffer
+    uint64_t n_slots = 0;        // physical slots in use (multiple of kTile)
+    uint32_t n_tiles = 0;
+    TileSum *sums[2] = {nullptr, nullptr};
+    int scur = 0;
+    unsigned long long *offsets = nullptr;
+
+    // pair table
+    PairTable tab = {};
+    uint32_t hcap = 0;
+    uint32_t *bp = nullptr;      // 65,536 byte-pair counts
+    DevCtl *ctl = nullptr;
+    unsigned long long *best = nullptr;   // [n_target + 1]
+    uint32_t *L = nullptr, *R = nullptr;  // [vocab_size] each, contiguous (L then R then gm,gadj)
+
+    // training
+    uint32_t vocab_size = 0;
+    uint32_t n_target = 0;
+    uint32_t k = 0;              // merges launched
+    uint32_t n_valid = 0;        // merges known to be real (table was not empty)
+    bool begun = false;
+    bool exhausted = false;
+    DevCtl h_ctl = {};
+
+    // options
+    int64_t opt_compact_den = 8;
+    int64_t opt_batch = 64;
+    int64_t opt_use_graph = 1;
+
+    mbpe_stats stats = {};
+};
+
+namespace {
+
+int sync_ctl(mbpe_ctx *c) {
+    HIPCHK(hipMemcpyAsync(&c->h_ctl, c->ctl, sizeof(DevCtl), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->h_ctl.err) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "device error flags 0x%x (1=pair table full, 2=negative count, 4=missing pair)",
+                 c->h_ctl.err);
+        mbpe_host::set_last_error(buf);
+        return MBPE_ERR_OVERFLOW;
+    }
+    return MBPE_OK;
+}
+
+void free_training(mbpe_ctx *c) {
+    dfree(c->tok[0]); dfree(c->tok[1]);
+    dfree(c->sums[0]); dfree(c->sums[1]);
+    dfree(c->offsets);
+    dfree(c->tab.hkey); dfree(c->tab.hidx); dfree(c->tab.ekey); dfree(c->tab.ecnt);
+    dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->L);
+    c->R = nullptr;
+    c->begun = false;
+    c->k = c->n_valid = 0;
+    c->exhausted = false;
+}
+
+void free_corpus(mbpe_ctx *c) {
+    dfree(c->d_text_owned);
+    dfree(c->d_endmask);
+    c->d_text = nullptr;
+    c->loaded = false;
+}
+
+int alloc_table(mbpe_ctx *c, uint32_t ecap) {
+    c->tab.ecap = ecap;
+    c->hcap = next_pow2((uint64_t)ecap * 2);
+    c->tab.hmask = c->hcap - 1;
+    HIPCHK(hipMalloc(&c->tab.hkey, (size_t)c->hcap * 4));
+    HIPCHK(hipMalloc(&c->tab.hidx, (size_t)c->hcap * 4));
+    HIPCHK(hipMalloc(&c->tab.ekey, (size_t)ecap * 4));
+    HIPCHK(hipMalloc(&c->tab.ecnt, (size_t)ecap * 4));
+    launch_fill_u32(c->stream, c->tab.hkey, c->hcap, kEmptyKey);
+    return MBPE_OK;
+}
+
+// entries a batch of `steps` merges can add at most: per merge one (x,X) per
+// left neighbour id, one (X,y) per right neighbour id and (X,X)
+uint64_t batch_headroom(const mbpe_ctx *c, uint32_t steps) {
+    uint64_t per = 2ull * c->vocab_size + 1;
+    return per * steps;
+}
+
+uint64_t table_cap_limit(const mbpe_ctx *c) {
+    uint64_t v = c->vocab_size;
+    uint64_t lim = v * v;                    // every possible pair
+    if (lim > 0xFFFFFFF0ull) lim = 0xFFFFFFF0ull;
+    return std::max<uint64_t>(lim, 1024);
+}
+
+int grow_table(mbpe_ctx *c, uint64_t want) {
+    uint64_t lim = table_cap_limit(c);
+    uint64_t ecap = std::min<uint64_t>(std::max<uint64_t>(want, (uint64_t)c->tab.ecap * 2), lim);
+    if (ecap <= c->tab.ecap) return MBPE_OK;   // already at the limit: cannot overflow
+    PairTable old = c->tab;
+    c->tab = {};
+    int rc = alloc_table(c, (uint32_t)ecap);
+    if (rc != MBPE_OK) return rc;
+    uint32_t n = c->h_ctl.n_entries;
+    HIPCHK(hipMemcpyAsync(c->tab.ekey, old.ekey, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->tab.ecnt, old.ecnt, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+    launch_table_rehash(c->stream, c->tab, c->ctl);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(old.hkey); (void)hipFree(old.hidx); (void)hipFree(old.ekey); (void)hipFree(old.ecnt);
+    return MBPE_OK;
+}
+
+int do_compact(mbpe_ctx *c) {
+    // c->h_ctl must be current
+    if (!c->n_tiles) return MBPE_OK;
+    const int src = c->cur, dst = 1 - c->cur;
+    launch_tile_scan(c->stream, c->sums[c->scur], c->n_tiles, c->offsets, c->ctl);
+    launch_compact_scatter(c->stream, c->tok[src], c->sums[c->scur], c->offsets, c->n_tiles, c->tok[dst]);
+    const uint64_t live = c->h_ctl.n_live;
+    const uint64_t padded = std::max<uint64_t>(round_up(live, kTile), kTile);
+    launch_fill_u16(c->stream, c->tok[dst] + live, padded - live, (uint16_t)kHole);
+    c->cur = dst;
+    c->n_slots = padded;
+    c->n_tiles = (uint32_t)(padded / kTile);
+    c->scur = 0;
+    launch_summarize(c->stream, c->tok[c->cur], c->sums[c->scur], c->n_tiles, c->ctl, 0);
+    DevCtl patch = c->h_ctl;
+    patch.removed_total = 0;
+    HIPCHK(hipMemcpyAsync(&c->ctl->removed_total, &patch.removed_total, sizeof(patch.removed_total),
+                          hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->h_ctl.removed_total = 0;
+    c->stats.n_compactions++;
+    return MBPE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mbpe_create(int device_id, mbpe_ctx **out) {
+    if (!out) { mbpe_host::set_last_error("mbpe_create: out is NULL"); return MBPE_ERR_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) {
+        mbpe_host::set_last_error("no usable HIP device (the MI355X path has no CPU fallback)");
+        return MBPE_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device_id));
+    mbpe_ctx *c = new mbpe_ctx();
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        mbpe_host::set_last_error("could not create HIP stream / events");
+        delete c;
+        return MBPE_ERR_HIP;
+    }
+    *out = c;
+    return MBPE_OK;
+}
+
+void mbpe_destroy(mbpe_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_training(c);
+    free_corpus(c);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return MBPE_ERR_ARG;
+    std::string n(name);
+    if (n == "compact_den") c->opt_compact_den = value;
+    else if (n == "batch") c->opt_batch = std::max<int64_t>(1, value);
+    else if (n == "use_graph") c->opt_use_graph = value;
+    else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
+    return MBPE_OK;
+}
+
+int mbpe_load_corpus(mbpe_ctx *c, const uint8_t *text, uint64_t n_bytes, const uint64_t *chunk_off,
+                     uint64_t n_chunks, int text_on_device) {
+    if (!c || (!text && n_bytes)) { mbpe_host::set_last_error("mbpe_load_corpus: NULL argument"); return MBPE_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    free_training(c);
+    free_corpus(c);
+    c->n_bytes = n_bytes;
+    c->chunked = chunk_off != nullptr;
+    c->n_chunks = chunk_off ? n_chunks : 1;
+    c->inert = false;
+    if (chunk_off) {
+        if (chunk_off[0] != 0 || chunk_off[n_chunks] != n_bytes) {
+            mbpe_host::set_last_error("chunk_off must start at 0 and end at n_bytes");
+            return MBPE_ERR_ARG;
+        }
+        for (uint64_t i = 0; i < n_chunks; ++i)
+            if (chunk_off[i] > chunk_off[i + 1]) {
+                mbpe_host::set_last_error("chunk_off must be ascending");
+                return MBPE_ERR_ARG;
+            }
+    }
+    if (text_on_device && ((uintptr_t)text & 15)) {
+        mbpe_host::set_last_error("device text must be 16-byte aligned");
+        return MBPE_ERR_ARG;
+    }
+
+    // host view of the text for the NUL-quirk check (Tokenizer.h:86-93)
+    std::vector<uint8_t> tmp;
+    const uint8_t *h_text = text;
+    if (text_on_device && n_bytes) {
+        bool need_all = chunk_off != nullptr;
+        uint64_t take = need_all ? n_bytes : std::min<uint64_t>(n_bytes, 64);
+        tmp.resize(take);
+        HIPCHK(hipMemcpy(tmp.data(), text, take, hipMemcpyDeviceToHost));
+        h_text = tmp.data();
+    }
+    const uint64_t n_vec = (n_bytes + 15) / 16;
+    std::vector<uint8_t> mask;
+    if (chunk_off) {
+        mask.assign(n_vec * 2 + 16, 0);
+        uint64_t dropped = 0;
+        for (uint64_t ci = 0; ci < n_chunks; ++ci) {
+            uint64_t s = chunk_off[ci], e = chunk_off[ci + 1];
+            if (e == s) continue;
+            mask[(e - 1) >> 3] |= (uint8_t)(1u << ((e - 1) & 7));
+            if (h_text[s] == 0 && stoi_parses(h_text + s + 1, e - s - 1)) {
+                // collapses to one token in the reference: no pair ever starts or ends
+                // inside it -> mark every byte as a chunk end so it stays inert
+                for (uint64_t i = s; i < e; ++i) mask[i >> 3] |= (uint8_t)(1u << (i & 7));
+                dropped++;
+            }
+        }
+        c->n_chunks = n_chunks - dropped;
+    } else if (n_bytes && h_text[0] == 0) {
+        // one chunk = whole text; stoi only looks at a prefix, 64 bytes are enough
+        // to decide unless the prefix is all whitespace (then parse the host copy)
+        uint64_t have = text_on_device ? tmp.size() : n_bytes;
+        bool parses = stoi_parses(h_text + 1, have - 1);
+        if (!parses && text_on_device && have < n_bytes) {
+            bool all_ws = true;
+            for (uint64_t i = 1; i < have; ++i)
+                if (!(h_text[i] == ' ' || (h_text[i] >= 9 && h_text[i] <= 13))) { all_ws = false; break; }
+            if (all_ws) {
+                tmp.resize(n_bytes);
+                HIPCHK(hipMemcpy(tmp.data(), text, n_bytes, hipMemcpyDeviceToHost));
+                parses = stoi_parses(tmp.data() + 1, n_bytes - 1);
+            }
+        }
+        c->inert = parses;
+        if (parses) c->n_chunks = 0;
+    }
+
+    if (text_on_device) {
+        c->d_text = text;
+    } else {
+        HIPCHK(hipMalloc(&c->d_text_owned, std::max<uint64_t>(n_vec * 16, 16)));
+        if (n_bytes) HIPCHK(hipMemcpyAsync(c->d_text_owned, text, n_bytes, hipMemcpyHostToDevice, c->stream));
+        c->d_text = c->d_text_owned;
+    }
+    if (chunk_off) {
+        HIPCHK(hipMalloc(&c->d_endmask, mask.size()));
+        HIPCHK(hipMemcpyAsync(c->d_endmask, mask.data(), mask.size(), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->loaded = true;
+    c->stats = {};
+    c->stats.n_bytes = n_bytes;
+    c->stats.n_chunks = c->n_chunks;
+    return MBPE_OK;
+}
+
+int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
+    if (!c) return MBPE_ERR_ARG;
+    if (!c->loaded) { mbpe_host::set_last_error("mbpe_pair_count_u8: no corpus loaded"); return MBPE_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t *bp = nullptr;
+    HIPCHK(hipMalloc(&bp, 65536 * 4));
+    HIPCHK(hipMemsetAsync(bp, 0, 65536 * 4, c->stream));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    if (!c->inert) launch_pair_count_u8(c->stream, c->d_text, c->n_bytes, c->d_endmask, bp, c->n_cus);
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess && table65536_out) e = hipMemcpy(table65536_out, bp, 65536 * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(bp);
+    if (e != hipSuccess) { mbpe_host::set_last_error(hip_err("pair count", e)); return MBPE_ERR_HIP; }
+    HIPCHK(hipEventElapsedTime(&c->stats.ms_pair_count, c->ev0, c->ev1));
+    c->stats.pair_count_launches++;
+    return MBPE_OK;
+}
+
+int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
+    if (!c) return MBPE_ERR_ARG;
+    if (!c->loaded) { mbpe_host::set_last_error("mbpe_train_begin: no corpus loaded"); return MBPE_ERR_STATE; }
+    if (vocab_size < 256) { mbpe_host::set_last_error("vocab_size must be >= 256"); return MBPE_ERR_ARG; }
+    const uint32_t vmax = c->chunked ? MBPE_MAX_VOCAB_CHUNKED : MBPE_MAX_VOCAB_BASIC;
+    if (vocab_size > vmax) {
+        mbpe_host::set_last_error("vocab_size exceeds the 16-bit slot format (" + std::to_string(vmax) + ")");
+        return MBPE_ERR_VOCAB;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    free_training(c);
+    c->vocab_size = vocab_size;
+    c->n_target = vocab_size - 256;
+    c->k = 0;
+    c->n_valid = 0;
+    c->exhausted = false;
+
+    const uint64_t n = c->inert ? 0 : c->n_bytes;
+    c->n_slots = std::max<uint64_t>(round_up(n, kTile), kTile);
+    c->cap_slots = c->n_slots;
+    c->n_tiles = (uint32_t)(c->n_slots / kTile);
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipMalloc(&c->tok[i], c->cap_slots * 2));
+        HIPCHK(hipMalloc(&c->sums[i], (size_t)c->n_tiles * sizeof(TileSum)));
+    }
+    HIPCHK(hipMalloc(&c->offsets, (size_t)c->n_tiles * 8));
+    HIPCHK(hipMalloc(&c->bp, 65536 * 4));
+    HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
+    HIPCHK(hipMalloc(&c->best, ((size_t)c->n_target + 2) * 8));
+    HIPCHK(hipMalloc(&c->L, ((size_t)vocab_size * 2 + 8) * 4));
+    c->R = c->L + vocab_size;
+    HIPCHK(hipMemsetAsync(c->bp, 0, 65536 * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(DevCtl), c->stream));
+    HIPCHK(hipMemsetAsync(c->best, 0, ((size_t)c->n_target + 2) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->L, 0, ((size_t)vocab_size * 2 + 8) * 4, c->stream));
+
+    uint64_t want = 65536 + 2 * batch_headroom(c, (uint32_t)c->opt_batch);
+    want = std::min<uint64_t>(want, table_cap_limit(c));
+    int rc = alloc_table(c, (uint32_t)want);
+    if (rc != MBPE_OK) return rc;
+
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    if (n >= 2) launch_pair_count_u8(c->stream, c->d_text, n, c->d_endmask, c->bp, c->n_cus);
+    launch_table_init(c->stream, c->bp, c->tab, c->ctl);
+    c->cur = 0;
+    c->scur = 0;
+    launch_widen(c->stream, c->d_text, n, c->d_endmask, c->tok[0], c->n_slots);
+    launch_summarize(c->stream, c->tok[0], c->sums[0], c->n_tiles, c->ctl, 1);
+    launch_argmax(c->stream, c->tab, c->ctl, c->best);
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    rc = sync_ctl(c);
+    if (rc != MBPE_OK) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventElapsedTime(&c->stats.ms_begin, c->ev0, c->ev1));
+    unsigned long long b0 = 0;
+    HIPCHK(hipMemcpy(&b0, c->best, 8, hipMemcpyDeviceToHost));
+    c->exhausted = (b0 == 0);   // empty table: the reference loop breaks at once (Tokenizer.h:586-588)
+    c->begun = true;
+    c->stats.ms_steps = 0;
+    return MBPE_OK;
+}
+
+int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
+    if (steps_done_out) *steps_done_out = 0;
+    if (!c) return MBPE_ERR_ARG;
+    if (!c->begun) { mbpe_host::set_last_error("mbpe_train_steps before mbpe_train_begin"); return MBPE_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t done = 0;
+    const uint32_t endbit = c->chunked ? kEndBit : 0;
+    while (done < n_steps && c->k < c->n_target && !c->exhausted) {
+        uint32_t batch = std::min<uint32_t>({(uint32_t)c->opt_batch, n_steps - done, c->n_target - c->k});
+        // pair-table headroom for this batch (h_ctl.n_entries is exact here)
+        if ((uint64_t)c->h_ctl.n_entries + batch_headroom(c, batch) > c->tab.ecap) {
+            int rc = grow_table(c, ((uint64_t)c->h_ctl.n_entries + batch_headroom(c, batch)) * 2);
+            if (rc != MBPE_OK) return rc;
+        }
+        HIPCHK(hipEventRecord(c->ev0, c->stream));
+        for (uint32_t i = 0; i < batch; ++i) {
+            const uint32_t X = 256 + c->k;
+            launch_merge(c->stream, c->tok[c->cur], c->sums[c->scur], c->sums[1 - c->scur], c->n_tiles,
+                         c->best + c->k, X, endbit, c->L, c->R, c->ctl, nullptr, nullptr);
+            c->scur = 1 - c->scur;
+            launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->L, c->R, nullptr);
+            launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1);
+            c->k++;
+        }
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        int rc = sync_ctl(c);
+        if (rc != MBPE_OK) return rc;
+        HIPCHK(hipGetLastError());
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->stats.ms_steps += ms;
+        done += batch;
+        c->n_valid = c->k;
+        if (c->opt_compact_den > 0 && c->h_ctl.removed_total * (uint64_t)c->opt_compact_den >= c->n_slots &&
+            c->h_ctl.removed_total > 0) {
+            rc = do_compact(c);
+            if (rc != MBPE_OK) return rc;
+        }
+    }
+    if (steps_done_out) *steps_done_out = done;
+    return MBPE_OK;
+}
+
+int mbpe_train_result(mbpe_ctx *c, uint32_t *merges_out, int32_t *counts_out, uint32_t cap_merges,
+                      uint32_t *n_merges_out) {
+    if (!c) return MBPE_ERR_ARG;
+    if (!c->begun) { mbpe_host::set_last_error("mbpe_train_result before mbpe_train_begin"); return MBPE_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t n = c->exhausted ? 0 : c->n_valid;
+    if (n_merges_out) *n_merges_out = n;
+    if (n > cap_merges && merges_out) { mbpe_host::set_last_error("merges_out too small"); return MBPE_ERR_ARG; }
+    if (!n || !merges_out) return MBPE_OK;
+    std::vector<unsigned long long> h(n);
+    HIPCHK(hipMemcpy(h.data(), c->best, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t key = ~(uint32_t)h[i];
+        merges_out[2 * i] = key >> 16;
+        merges_out[2 * i + 1] = key & 0xFFFFu;
+        if (counts_out) counts_out[i] = (int32_t)(h[i] >> 32);
+    }
+    return MBPE_OK;
+}
+
+int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
+    if (!c || !out) return MBPE_ERR_ARG;
+    c->stats.n_slots = c->begun ? c->n_slots : 0;
+    c->stats.n_live = c->begun ? c->h_ctl.n_live : 0;
+    c->stats.n_merges = c->exhausted ? 0 : c->n_valid;
+    c->stats.n_pairs = c->begun ? c->h_ctl.n_entries : 0;
+    *out = c->stats;
+    return MBPE_OK;
+}
+
+int mbpe_train_lexical(mbpe_ctx *c, const uint8_t *text, uint64_t n_bytes, const uint64_t *chunk_off,
+                       uint64_t n_chunks, uint32_t vocab_size, uint32_t *merges_out, int32_t *counts_out,
+                       uint32_t *n_merges_out, mbpe_stats *stats_out) {
+    if (!c || !merges_out) { mbpe_host::set_last_error("mbpe_train_lexical: NULL argument"); return MBPE_ERR_ARG; }
+    int rc = mbpe_load_corpus(c, text, n_bytes, chunk_off, n_chunks, 0);
+    if (rc != MBPE_OK) return rc;
+    rc = mbpe_train_begin(c, vocab_size);
+    if (rc != MBPE_OK) return rc;
+    rc = mbpe_train_steps(c, vocab_size - 256, nullptr);
+    if (rc != MBPE_OK) return rc;
+    rc = mbpe_train_result(c, merges_out, counts_out, vocab_size - 256, n_merges_out);
+    if (rc != MBPE_OK) return rc;
+    if (stats_out) mbpe_get_stats(c, stats_out);
+    return MBPE_OK;
+}
+
+int mbpe_get_stream(mbpe_ctx *c, uint32_t *tokens_out, uint8_t *chunk_end_out, uint64_t cap, uint64_t *n_out) {
+    if (!c || !n_out) return MBPE_ERR_ARG;
+    if (!c->begun) { mbpe_host::set_last_error("mbpe_get_stream before mbpe_train_begin"); return MBPE_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<uint16_t> h(c->n_slots);
+    HIPCHK(hipMemcpy(h.data(), c->tok[c->cur], c->n_slots * 2, hipMemcpyDeviceToHost));
+    const uint32_t idmask = c->chunked ? 0x7FFFu : 0xFFFFu;
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < c->n_slots; ++i) {
+        if (h[i] == kHole) continue;
+        if (tokens_out) {
+            if (w >= cap) { mbpe_host::set_last_error("tokens_out too small"); return MBPE_ERR_ARG; }
+            tokens_out[w] = h[i] & idmask;
+            if (chunk_end_out) chunk_end_out[w] = c->chunked ? (h[i] >> 15) & 1 : 0;
+        }
+        ++w;
+    }
+    *n_out = w;
+    return MBPE_OK;
+}
+
+int mbpe_get_pairs(mbpe_ctx *c, uint32_t *first_out, uint32_t *second_out, int32_t *count_out, uint64_t cap,
+                   uint64_t *n_out) {
+    if (!c || !n_out) return MBPE_ERR_ARG;
+    if (!c->begun) { mbpe_host::set_last_error("mbpe_get_pairs before mbpe_train_begin"); return MBPE_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = sync_ctl(c);
+    if (rc != MBPE_OK) return rc;
+    const uint64_t n = c->h_ctl.n_entries;
+    *n_out = n;
+    if (!first_out) return MBPE_OK;
+    if (cap < n) { mbpe_host::set_last_error("pair arrays too small"); return MBPE_ERR_ARG; }
+    std::vector<uint32_t> keys(n);
+    std::vector<int32_t> cnts(n);
+    if (n) {
+        HIPCHK(hipMemcpy(keys.data(), c->tab.ekey, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(cnts.data(), c->tab.ecnt, n * 4, hipMemcpyDeviceToHost));
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        first_out[i] = keys[i] >> 16;
+        second_out[i] = keys[i] & 0xFFFFu;
+        if (count_out) count_out[i] = cnts[i];
+    }
+    return MBPE_OK;
+}
+
+int mbpe_compact(mbpe_ctx *c) {
+    if (!c) return MBPE_ERR_ARG;
+    if (!c->begun) { mbpe_host::set_last_error("mbpe_compact before mbpe_train_begin"); return MBPE_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = sync_ctl(c);
+    if (rc != MBPE_OK) return rc;
+    return do_compact(c);
+}
+
+int mbpe_comm_unique_id(uint8_t *) {
+    mbpe_host::set_last_error("multi-GPU support not built yet");
+    return MBPE_ERR_COMM;
+}
+
+int mbpe_comm_init(mbpe_ctx *, const uint8_t *, int, int) {
+    mbpe_host::set_last_error("multi-GPU support not built yet");
+    return MBPE_ERR_COMM;
+}
+
+}  // extern "C"

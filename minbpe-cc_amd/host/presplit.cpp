@@ -114,6 +114,8 @@ int Splitter::split(const uint8_t *text, uint64_t n, std::vector<uint64_t> *star
         return MBPE_OK;
     }
     Pcre2Api &p = pcre2();
+    static const uint8_t kEmpty[1] = {0};
+    if (!text) text = kEmpty;      // std::string::data() of an empty string is never NULL
     size_t offset = 0;
     for (;;) {
         int rc = p.match(code_, text, n, offset, kPCRE2_NO_UTF_CHECK, match_data_, nullptr);

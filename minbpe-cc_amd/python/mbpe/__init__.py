@@ -1,0 +1,241 @@
+"""ctypes binding of the C-ABI in include/mbpe.h (libmbpe.so).
+
+Used by tests/, bench.py and __graft_entry__.py.  The library itself is the
+product; this file only marshals numpy arrays / device pointers into it.
+There is no fallback: if libmbpe.so is missing, import-time use raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_PATH = os.path.join(_PKG_DIR, "libmbpe.so")
+
+OK = 0
+ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_VOCAB, ERR_STATE = -1, -2, -3, -4, -5
+ERR_OOM, ERR_REGEX, ERR_SPLIT_GAP, ERR_COMM, ERR_OVERFLOW, ERR_IO = -6, -7, -8, -9, -10, -11
+COMM_ID_BYTES = 128
+
+# every symbol include/mbpe.h declares
+EXPORTS = [
+    "mbpe_last_error", "mbpe_version", "mbpe_create", "mbpe_destroy", "mbpe_load_corpus",
+    "mbpe_pair_count_u8", "mbpe_train_begin", "mbpe_train_steps", "mbpe_train_result",
+    "mbpe_train_lexical", "mbpe_get_stats", "mbpe_get_stream", "mbpe_get_pairs", "mbpe_compact",
+    "mbpe_set_option", "mbpe_comm_unique_id", "mbpe_comm_init", "mbpe_presplit",
+    "mbpe_split_count", "mbpe_split_offsets", "mbpe_split_free", "mbpe_split_pattern",
+]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("n_bytes", ctypes.c_uint64), ("n_chunks", ctypes.c_uint64), ("n_slots", ctypes.c_uint64),
+        ("n_live", ctypes.c_uint64), ("n_merges", ctypes.c_uint32), ("n_compactions", ctypes.c_uint32),
+        ("n_pairs", ctypes.c_uint64), ("ms_pair_count", ctypes.c_float), ("ms_begin", ctypes.c_float),
+        ("ms_steps", ctypes.c_float), ("pair_count_launches", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class MbpeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mbpe error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libmbpe.so is not built (%s); run __graft_entry__.build()" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u64, u32, i32, i64 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_int64
+    L.mbpe_last_error.restype = ctypes.c_char_p
+    L.mbpe_version.restype = ctypes.c_char_p
+    L.mbpe_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.mbpe_destroy.argtypes = [vp]
+    L.mbpe_destroy.restype = None
+    L.mbpe_load_corpus.argtypes = [vp, vp, u64, vp, u64, i32]
+    L.mbpe_pair_count_u8.argtypes = [vp, vp]
+    L.mbpe_train_begin.argtypes = [vp, u32]
+    L.mbpe_train_steps.argtypes = [vp, u32, vp]
+    L.mbpe_train_result.argtypes = [vp, vp, vp, u32, vp]
+    L.mbpe_train_lexical.argtypes = [vp, vp, u64, vp, u64, u32, vp, vp, vp, vp]
+    L.mbpe_get_stats.argtypes = [vp, vp]
+    L.mbpe_get_stream.argtypes = [vp, vp, vp, u64, vp]
+    L.mbpe_get_pairs.argtypes = [vp, vp, vp, vp, u64, vp]
+    L.mbpe_compact.argtypes = [vp]
+    L.mbpe_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+    L.mbpe_comm_unique_id.argtypes = [vp]
+    L.mbpe_comm_init.argtypes = [vp, vp, i32, i32]
+    L.mbpe_presplit.argtypes = [ctypes.c_char_p, vp, u64, ctypes.POINTER(vp)]
+    L.mbpe_split_count.argtypes = [vp]
+    L.mbpe_split_count.restype = u64
+    L.mbpe_split_offsets.argtypes = [vp]
+    L.mbpe_split_offsets.restype = ctypes.POINTER(ctypes.c_uint64)
+    L.mbpe_split_free.argtypes = [vp]
+    L.mbpe_split_free.restype = None
+    L.mbpe_split_pattern.argtypes = [ctypes.c_char_p]
+    L.mbpe_split_pattern.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise MbpeError(rc, lib().mbpe_last_error().decode("utf-8", "replace"))
+
+
+def _u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(data, dtype=np.uint8)
+
+
+def split_pattern(encoder):
+    p = lib().mbpe_split_pattern(encoder.encode())
+    if p is None:
+        raise ValueError("Encoder should be one of: basic, gpt2 or gpt4")
+    return p.decode("utf-8")
+
+
+def presplit(pattern, data):
+    """Tokenizer::train's regex pre-split (Tokenizer.h:500-540) -> uint64 offsets [n_chunks+1]."""
+    text = _u8(data)
+    h = ctypes.c_void_p()
+    _check(lib().mbpe_presplit(pattern.encode("utf-8"), text.ctypes.data if len(text) else None,
+                               len(text), ctypes.byref(h)))
+    try:
+        n = lib().mbpe_split_count(h)
+        return np.ctypeslib.as_array(lib().mbpe_split_offsets(h), shape=(n + 1,)).copy()
+    finally:
+        lib().mbpe_split_free(h)
+
+
+class Trainer:
+    """One mbpe_ctx.  Mirrors the order of Tokenizer::train (Tokenizer.h:489-598)."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        _check(lib().mbpe_create(device, ctypes.byref(self._h)))
+        self._keep = None
+        self.vocab_size = 0
+
+    def close(self):
+        if self._h:
+            lib().mbpe_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_option(self, name, value):
+        _check(lib().mbpe_set_option(self._h, name.encode(), int(value)))
+
+    def load_corpus(self, data, chunk_off=None):
+        text = _u8(data)
+        off = None if chunk_off is None else np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        self._keep = (text, off)
+        _check(lib().mbpe_load_corpus(self._h, text.ctypes.data if len(text) else None, len(text),
+                                      None if off is None else off.ctypes.data,
+                                      0 if off is None else len(off) - 1, 0))
+
+    def load_corpus_device(self, dev_ptr, n_bytes, chunk_off=None, keep=None):
+        """dev_ptr: device address of n_bytes corpus bytes (e.g. torch tensor .data_ptr())."""
+        off = None if chunk_off is None else np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        self._keep = (keep, off)
+        _check(lib().mbpe_load_corpus(self._h, ctypes.c_void_p(dev_ptr), n_bytes,
+                                      None if off is None else off.ctypes.data,
+                                      0 if off is None else len(off) - 1, 1))
+
+    def pair_count_u8(self, want_table=True):
+        table = np.zeros(65536, dtype=np.uint32) if want_table else None
+        _check(lib().mbpe_pair_count_u8(self._h, None if table is None else table.ctypes.data))
+        return table
+
+    def train_begin(self, vocab_size):
+        _check(lib().mbpe_train_begin(self._h, vocab_size))
+        self.vocab_size = vocab_size
+
+    def train_steps(self, n_steps):
+        done = ctypes.c_uint32()
+        _check(lib().mbpe_train_steps(self._h, n_steps, ctypes.byref(done)))
+        return done.value
+
+    def train_result(self):
+        cap = max(self.vocab_size - 256, 1)
+        merges = np.zeros((cap, 2), dtype=np.uint32)
+        counts = np.zeros(cap, dtype=np.int32)
+        n = ctypes.c_uint32()
+        _check(lib().mbpe_train_result(self._h, merges.ctypes.data, counts.ctypes.data, cap, ctypes.byref(n)))
+        return merges[:n.value].copy(), counts[:n.value].copy()
+
+    def train_lexical(self, data, vocab_size, chunk_off=None):
+        text = _u8(data)
+        off = None if chunk_off is None else np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        cap = max(vocab_size - 256, 1)
+        merges = np.zeros((cap, 2), dtype=np.uint32)
+        counts = np.zeros(cap, dtype=np.int32)
+        n = ctypes.c_uint32()
+        st = Stats()
+        _check(lib().mbpe_train_lexical(self._h, text.ctypes.data if len(text) else None, len(text),
+                                        None if off is None else off.ctypes.data,
+                                        0 if off is None else len(off) - 1, vocab_size,
+                                        merges.ctypes.data, counts.ctypes.data, ctypes.byref(n),
+                                        ctypes.byref(st)))
+        self.vocab_size = vocab_size
+        return merges[:n.value].copy(), counts[:n.value].copy(), st.as_dict()
+
+    def stats(self):
+        st = Stats()
+        _check(lib().mbpe_get_stats(self._h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def stream(self):
+        n = ctypes.c_uint64()
+        _check(lib().mbpe_get_stream(self._h, None, None, 0, ctypes.byref(n)))
+        toks = np.zeros(max(n.value, 1), dtype=np.uint32)
+        ends = np.zeros(max(n.value, 1), dtype=np.uint8)
+        _check(lib().mbpe_get_stream(self._h, toks.ctypes.data, ends.ctypes.data, n.value, ctypes.byref(n)))
+        return toks[:n.value], ends[:n.value]
+
+    def pairs(self):
+        n = ctypes.c_uint64()
+        _check(lib().mbpe_get_pairs(self._h, None, None, None, 0, ctypes.byref(n)))
+        a = np.zeros(max(n.value, 1), dtype=np.uint32)
+        b = np.zeros(max(n.value, 1), dtype=np.uint32)
+        c = np.zeros(max(n.value, 1), dtype=np.int32)
+        _check(lib().mbpe_get_pairs(self._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, n.value, ctypes.byref(n)))
+        return a[:n.value], b[:n.value], c[:n.value]
+
+    def pairs_dict(self):
+        a, b, c = self.pairs()
+        return {(int(x), int(y)): int(z) for x, y, z in zip(a, b, c)}
+
+    def compact(self):
+        _check(lib().mbpe_compact(self._h))
+
+    def comm_init(self, uid, rank, n_ranks):
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+        _check(lib().mbpe_comm_init(self._h, buf, rank, n_ranks))
+
+
+def comm_unique_id():
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().mbpe_comm_unique_id(buf))
+    return bytes(buf)

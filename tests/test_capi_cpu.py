@@ -1,0 +1,73 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol of
+include/mbpe.h, fails loudly without a GPU, and the host pre-split works."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mbpe
+import oracle as O
+from conftest import ROOT, read_data
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mbpe.h")).read()
+    declared = set(re.findall(r"MBPE_API[^;]*?\b(mbpe_\w+)\s*\(", header))
+    assert declared == set(mbpe.EXPORTS)
+    L = mbpe.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+    assert b"gfx950" in L.mbpe_version()
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device failure path")
+def test_no_silent_cpu_fallback():
+    with pytest.raises(mbpe.MbpeError) as e:
+        mbpe.Trainer(0)
+    assert e.value.code == mbpe.ERR_NO_DEVICE
+
+
+def test_split_patterns_are_the_reference_strings():
+    assert mbpe.split_pattern("gpt2") == O.GPT2_SPLIT_PATTERN
+    assert mbpe.split_pattern("gpt4") == O.GPT4_SPLIT_PATTERN
+    assert mbpe.split_pattern("basic") == ""
+    with pytest.raises(ValueError):
+        mbpe.split_pattern("gpt5")
+
+
+def test_presplit_chunk_counts():
+    # taylorswift gpt4 = 46,196 chunks; shakespeare gpt4 = 263,198
+    ts = read_data("taylorswift.txt")
+    off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, ts)
+    assert len(off) - 1 == 46196 and off[0] == 0 and off[-1] == len(ts)
+    assert np.all(np.diff(off.astype(np.int64)) > 0)
+    sh = read_data("shakespeare.txt")
+    assert len(mbpe.presplit(O.GPT4_SPLIT_PATTERN, sh)) - 1 == 263198
+
+
+def test_presplit_against_python_regex():
+    regex = pytest.importorskip("regex")
+    data = read_data("sample.txt")          # UTF-8 with emoji
+    text = data.decode("utf-8")
+    for pat in (O.GPT2_SPLIT_PATTERN, O.GPT4_SPLIT_PATTERN):
+        off = mbpe.presplit(pat, data)
+        pieces = [data[off[i]:off[i + 1]].decode("utf-8") for i in range(len(off) - 1)]
+        assert pieces == regex.findall(pat, text)
+
+
+def test_presplit_basic_and_empty():
+    assert mbpe.presplit("", b"hello").tolist() == [0, 5]
+    assert mbpe.presplit(O.GPT4_SPLIT_PATTERN, b"").tolist() == [0]
+
+
+def test_presplit_bad_pattern():
+    with pytest.raises(mbpe.MbpeError) as e:
+        mbpe.presplit("(unclosed", b"abc")
+    assert e.value.code == mbpe.ERR_REGEX

@@ -1,0 +1,224 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (libmbpe.so),
+against the CPU oracle and the golden fixtures.  Integer work: bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import mbpe
+import oracle as O
+from conftest import GOLDEN, read_data, read_golden
+
+pytestmark = pytest.mark.gpu
+
+INDEX = json.load(open(os.path.join(GOLDEN, "index.json")))
+LEXICAL_GOLDENS = sorted(k for k, v in INDEX.items() if v["mode"] == "lexical")
+
+
+@pytest.fixture(scope="module")
+def tr():
+    t = mbpe.Trainer(0)
+    yield t
+    t.close()
+
+
+def _input(spec):
+    if spec.startswith("splitmix:"):
+        _, seed, n = spec.split(":")
+        return O.splitmix64_bytes(int(seed), int(n)).tobytes()
+    return read_data(spec)
+
+
+def _random_chunks(rng, n, mean):
+    if n == 0:
+        return np.array([0], dtype=np.uint64)
+    cuts = np.unique(rng.integers(1, max(n, 2), size=max(n // mean, 1)))
+    cuts = cuts[cuts < n]
+    return np.concatenate([[0], cuts, [n]]).astype(np.uint64)
+
+
+# ---------------------------------------------------------------- pair count
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 1023, 16384, 16385, 100003])
+def test_pair_count_sizes(tr, n):
+    rng = np.random.default_rng(n)
+    data = rng.integers(0, 256, size=n, dtype=np.uint8)
+    if n:
+        data[0] = 1
+    tr.load_corpus(data)
+    assert np.array_equal(tr.pair_count_u8(), O.pair_count_u8(data))
+
+
+def test_pair_count_random_1mib(tr):
+    data = O.splitmix64_bytes(42, 1 << 20)
+    tr.load_corpus(data)
+    assert np.array_equal(tr.pair_count_u8(), O.pair_count_u8(data))
+
+
+def test_pair_count_text_and_chunks(tr):
+    data = read_data("shakespeare.txt")
+    tr.load_corpus(data)
+    assert np.array_equal(tr.pair_count_u8(), O.pair_count_u8(data))
+    off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data)
+    tr.load_corpus(data, off)
+    assert np.array_equal(tr.pair_count_u8(), O.pair_count_u8(data, off))
+
+
+def test_pair_count_16bit_counter_drain(tr):
+    # one pair far beyond 65,535 per workgroup: exercises the epoch drain of the
+    # packed 16-bit LDS counters
+    n = 24 << 20
+    data = np.full(n, 97, dtype=np.uint8)
+    data[5::1000] = 98
+    tr.load_corpus(data)
+    got = tr.pair_count_u8()
+    assert np.array_equal(got, O.pair_count_u8(data))
+    assert int(got[(97 << 8) | 97]) > (1 << 24)
+
+
+def test_pair_count_random_chunks(tr):
+    rng = np.random.default_rng(11)
+    for n in (50, 4097, 70001):
+        data = rng.integers(97, 123, size=n, dtype=np.uint8)
+        off = _random_chunks(rng, n, 5)
+        tr.load_corpus(data, off)
+        assert np.array_equal(tr.pair_count_u8(), O.pair_count_u8(data, off))
+
+
+# ---------------------------------------------------------------- training
+@pytest.mark.parametrize("name", LEXICAL_GOLDENS)
+def test_train_golden_model_bytes(tr, name):
+    meta = INDEX[name]
+    data = _input(meta["input"])
+    enc = meta["encoder"]
+    off = None if enc == "basic" else mbpe.presplit(O.PATTERNS[enc], data)
+    merges, counts, stats = tr.train_lexical(data, meta["vocab"], off)
+    assert O.model_bytes(O.PATTERNS[enc], merges) == read_golden(name + ".model")
+    assert int(counts[0]) == meta["first_count"] and int(counts[-1]) == meta["last_count"]
+    assert stats["n_live"] == len(data) - int(counts.sum())
+
+
+def test_train_kat_small_and_aaaa(tr):
+    m, c, _ = tr.train_lexical(read_data("small.txt"), 275)
+    want = [[98, 99], [100, 101], [256, 257], [258, 258], [97, 259], [258, 10], [260, 261]] + [[97, 98]] * 12
+    assert m.tolist() == want and c.tolist()[7:] == [0] * 12
+    m, c, _ = tr.train_lexical(b"aaaa", 262)
+    assert m.tolist() == [[97, 97], [256, 256], [97, 97], [97, 97], [97, 97], [97, 97]]
+    assert c.tolist() == [3, 1, 0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("data,vocab", [(b"", 300), (b"a", 300), (b"ab", 258), (b"\x00123abcabc", 260),
+                                        (b"\x00abcabc", 258), (b"abcbcde", 259)])
+def test_train_tiny_inputs(tr, data, vocab):
+    want_m, want_c = O.train(data, vocab)
+    m, c, _ = tr.train_lexical(data, vocab)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
+def _step_parity(tr, data, off, vocab, **opts):
+    """Every step: chosen pair, count, live stream, chunk ends and the whole pair table."""
+    for k, v in opts.items():
+        tr.set_option(k, v)
+    try:
+        st = O.State(data, off)
+        tr.load_corpus(data, off)
+        tr.train_begin(vocab)
+        for i in range(vocab - 256):
+            top = st.top()
+            done = tr.train_steps(1)
+            if top is None:
+                assert done == 0 or len(tr.train_result()[0]) == 0
+                break
+            m, c = tr.train_result()
+            assert (int(m[i][0]), int(m[i][1]), int(c[i])) == top, "step %d" % i
+            st.merge(top[0], top[1], 256 + i)
+            want_toks, want_clen = st.stream()
+            toks, ends = tr.stream()
+            assert np.array_equal(toks, want_toks), "stream differs at step %d" % i
+            if off is not None:
+                pos = np.cumsum(want_clen[want_clen > 0]).astype(np.int64) - 1
+                want_ends = np.zeros(len(want_toks), dtype=np.uint8)
+                want_ends[pos] = 1
+                assert np.array_equal(ends, want_ends), "chunk ends differ at step %d" % i
+            want_tab = {k_: v_ for k_, v_ in st.table_dict().items() if v_}
+            got_tab = {k_: v_ for k_, v_ in tr.pairs_dict().items() if v_}
+            assert got_tab == want_tab, "pair table differs at step %d" % i
+    finally:
+        tr.set_option("compact_den", 8)
+        tr.set_option("batch", 64)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_step_parity_small_alphabet(tr, seed):
+    # 2-4 symbols: long runs (a==b merges), touching matches ("abab"), dense holes
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 6000))
+    data = rng.integers(97, 97 + int(rng.integers(1, 5)), size=n, dtype=np.uint8)
+    _step_parity(tr, data, None, 256 + 40, batch=1, compact_den=int(rng.integers(0, 9)))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_step_parity_chunked(tr, seed):
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(2, 9000))
+    data = rng.integers(97, 97 + int(rng.integers(1, 6)), size=n, dtype=np.uint8)
+    off = _random_chunks(rng, n, int(rng.integers(2, 12)))
+    _step_parity(tr, data, off, 256 + 40, batch=1, compact_den=int(rng.integers(0, 9)))
+
+
+def test_step_parity_runs_across_tiles(tr):
+    # runs of one byte far longer than a 2048-slot tile, odd and even lengths
+    parts = [b"a" * 5001, b"b", b"a" * 4096, b"cc", b"a" * 2047, b"d", b"a" * 2049, b"ab" * 3000]
+    _step_parity(tr, b"".join(parts), None, 256 + 24, batch=1, compact_den=3)
+
+
+def test_step_parity_text_gpt4(tr):
+    data = read_data("taylorswift.txt")[:60000]
+    off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data)
+    _step_parity(tr, data, off, 256 + 48, batch=1)
+
+
+@pytest.mark.parametrize("batch,den", [(1, 1), (7, 2), (64, 0), (256, 8)])
+def test_train_options_do_not_change_results(tr, batch, den):
+    data = read_data("taylorswift.txt")
+    want_m, want_c = O.train(data, 400)
+    tr.set_option("batch", batch)
+    tr.set_option("compact_den", den)
+    try:
+        m, c, st = tr.train_lexical(data, 400)
+    finally:
+        tr.set_option("batch", 64)
+        tr.set_option("compact_den", 8)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+    if den == 1:
+        assert st["n_compactions"] > 0
+
+
+def test_train_is_deterministic(tr):
+    data = O.splitmix64_bytes(5, 300000)
+    a = tr.train_lexical(data, 700)
+    b = tr.train_lexical(data, 700)
+    assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+
+
+def test_vocab_limits(tr):
+    data = b"hello world hello world"
+    tr.load_corpus(data)
+    with pytest.raises(mbpe.MbpeError) as e:
+        tr.train_begin(255)
+    assert e.value.code == mbpe.ERR_ARG
+    with pytest.raises(mbpe.MbpeError) as e:
+        tr.train_begin(65535)
+    assert e.value.code == mbpe.ERR_VOCAB
+    tr.load_corpus(data, np.array([0, 5, len(data)], dtype=np.uint64))
+    with pytest.raises(mbpe.MbpeError) as e:
+        tr.train_begin(32767)
+    assert e.value.code == mbpe.ERR_VOCAB
+
+
+def test_large_vocab_many_merges(tr):
+    # vocab 4096 on 256 KiB of random bytes: table growth + thousands of steps
+    data = O.splitmix64_bytes(9, 1 << 18)
+    want_m, want_c = O.train(data, 4096)
+    m, c, _ = tr.train_lexical(data, 4096)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
