@@ -64,7 +64,23 @@ def main():
     for name, spec, enc, mode, vocab, sha in CASES:
         data = load_input(spec)
         off = None if enc == "basic" else mbpe.presplit(O.PATTERNS[enc], data)
-        merges, counts = O.train(data, vocab, off, O.LEXICAL if mode == "lexical" else O.FIRST)
+        omode = O.LEXICAL if mode == "lexical" else O.FIRST
+        st = O.State(data, off, omode)
+        merges_l, counts_l = [], []
+        for i in range(vocab - 256):
+            top = st.top()
+            if top is None:
+                break
+            merges_l.append(top[:2])
+            counts_l.append(top[2])
+            st.merge(top[0], top[1], 256 + i)
+        final_len = int(len(st.stream()[0]))
+        st.close()
+        import numpy as np
+        merges = np.array(merges_l, dtype=np.uint32).reshape(-1, 2)
+        counts = np.array(counts_l, dtype=np.int32)
+        m2, c2 = O.train(data, vocab, off, omode)
+        assert m2.tolist() == merges.tolist() and c2.tolist() == counts.tolist()
         blob = O.model_bytes(O.PATTERNS[enc], merges)
         got = hashlib.sha256(blob).hexdigest()
         if got != sha:
@@ -73,7 +89,8 @@ def main():
             f.write(blob)
         index[name] = {"input": spec, "encoder": enc, "mode": mode, "vocab": vocab,
                        "sha256": sha, "bytes": len(blob),
-                       "first_count": int(counts[0]), "last_count": int(counts[-1])}
+                       "first_count": int(counts[0]), "last_count": int(counts[-1]),
+                       "final_len": final_len}
         print("ok", name, len(blob))
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)

@@ -95,7 +95,8 @@ def test_train_golden_model_bytes(tr, name):
     merges, counts, stats = tr.train_lexical(data, meta["vocab"], off)
     assert O.model_bytes(O.PATTERNS[enc], merges) == read_golden(name + ".model")
     assert int(counts[0]) == meta["first_count"] and int(counts[-1]) == meta["last_count"]
-    assert stats["n_live"] == len(data) - int(counts.sum())
+    # (a merge of (t,t) removes fewer tokens than its overlapping-window count)
+    assert stats["n_live"] == meta["final_len"] >= len(data) - int(counts.sum())
 
 
 def test_train_kat_small_and_aaaa(tr):
@@ -154,7 +155,7 @@ def test_step_parity_small_alphabet(tr, seed):
     rng = np.random.default_rng(seed)
     n = int(rng.integers(1, 6000))
     data = rng.integers(97, 97 + int(rng.integers(1, 5)), size=n, dtype=np.uint8)
-    _step_parity(tr, data, None, 256 + 40, batch=1, compact_den=int(rng.integers(0, 9)))
+    _step_parity(tr, data, None, 256 + 40, batch=1, compact_den=int(rng.choice([0, 2, 3, 8, 50, 100000])))
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -163,7 +164,7 @@ def test_step_parity_chunked(tr, seed):
     n = int(rng.integers(2, 9000))
     data = rng.integers(97, 97 + int(rng.integers(1, 6)), size=n, dtype=np.uint8)
     off = _random_chunks(rng, n, int(rng.integers(2, 12)))
-    _step_parity(tr, data, off, 256 + 40, batch=1, compact_den=int(rng.integers(0, 9)))
+    _step_parity(tr, data, off, 256 + 40, batch=1, compact_den=int(rng.choice([0, 2, 3, 8, 50, 100000])))
 
 
 def test_step_parity_runs_across_tiles(tr):
@@ -178,7 +179,7 @@ def test_step_parity_text_gpt4(tr):
     _step_parity(tr, data, off, 256 + 48, batch=1)
 
 
-@pytest.mark.parametrize("batch,den", [(1, 1), (7, 2), (64, 0), (256, 8)])
+@pytest.mark.parametrize("batch,den", [(1, 1000), (7, 16), (64, 0), (256, 8)])
 def test_train_options_do_not_change_results(tr, batch, den):
     data = read_data("taylorswift.txt")
     want_m, want_c = O.train(data, 400)
