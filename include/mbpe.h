@@ -66,6 +66,8 @@ typedef struct {
     float    ms_begin;         /* widen + table build + first argmax */
     float    ms_steps;         /* all merge steps so far */
     uint32_t pair_count_launches;
+    uint32_t merge_launches;   /* merge-kernel launches timed ("time_kernels" option) */
+    float    ms_merge_kernel;  /* summed duration of those launches */
     uint32_t reserved;
 } mbpe_stats;
 
@@ -160,6 +162,8 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *   "compact_den"   compact when holes * den >= slots (default 8; 0 = never)
  *   "batch"         merges per host round trip (default 64)
  *   "use_graph"     1 = replay merges from a captured hipGraph (default 1)
+ *   "time_kernels"  1 = bracket every merge kernel with HIP events on the
+ *                   context's stream; totals appear in mbpe_stats
  */
 MBPE_API int mbpe_set_option(mbpe_ctx *ctx, const char *name, int64_t value);
 

@@ -116,6 +116,8 @@ struct mbpe_ctx {
     int64_t opt_compact_den = 8;
     int64_t opt_batch = 64;
     int64_t opt_use_graph = 1;
+    int64_t opt_time_kernels = 0;   // HIP events around every merge kernel (bench.py)
+    std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
 
     mbpe_stats stats = {};
 };
@@ -255,6 +257,7 @@ void mbpe_destroy(mbpe_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_training(c);
     free_corpus(c);
+    for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -267,6 +270,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     if (n == "compact_den") c->opt_compact_den = value;
     else if (n == "batch") c->opt_batch = std::max<int64_t>(1, value);
     else if (n == "use_graph") c->opt_use_graph = value;
+    else if (n == "time_kernels") c->opt_time_kernels = value;
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
 }
@@ -458,11 +462,20 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
             int rc = grow_table(c, ((uint64_t)c->h_ctl.n_entries + batch_headroom(c, batch)) * 2);
             if (rc != MBPE_OK) return rc;
         }
+        if (c->opt_time_kernels) {
+            while (c->kev.size() < 2ull * batch) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));
+                c->kev.push_back(e);
+            }
+        }
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         for (uint32_t i = 0; i < batch; ++i) {
             const uint32_t X = 256 + c->k;
+            if (c->opt_time_kernels) HIPCHK(hipEventRecord(c->kev[2 * i], c->stream));
             launch_merge(c->stream, c->tok[c->cur], c->sums[c->scur], c->sums[1 - c->scur], c->n_tiles,
                          c->best + c->k, X, endbit, c->L, c->R, c->ctl, nullptr, nullptr);
+            if (c->opt_time_kernels) HIPCHK(hipEventRecord(c->kev[2 * i + 1], c->stream));
             c->scur = 1 - c->scur;
             launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->L, c->R, nullptr);
             launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1);
@@ -475,6 +488,14 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->stats.ms_steps += ms;
+        if (c->opt_time_kernels) {
+            for (uint32_t i = 0; i < batch; ++i) {
+                float km = 0;
+                HIPCHK(hipEventElapsedTime(&km, c->kev[2 * i], c->kev[2 * i + 1]));
+                c->stats.ms_merge_kernel += km;
+                c->stats.merge_launches++;
+            }
+        }
         done += batch;
         c->n_valid = c->k;
         if (c->opt_compact_den > 0 && c->h_ctl.removed_total * (uint64_t)c->opt_compact_den >= c->n_slots &&
