@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (kernel_stats / counter_collection) into the
+small per-kernel summaries committed under profiles/.
+
+usage: summarize.py stats <kernel_stats.csv> | pmc <counter_collection.csv>
+PMC note (guide: /opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE and
+WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half the bytes of a wide
+coalesced read, so the corrected read traffic is 2 x FETCH_SIZE x 1024.
+"""
+import collections
+import csv
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"(k_\w+)(<\w+>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else None
+
+
+def main():
+    mode, path = sys.argv[1], sys.argv[2]
+    if mode == "stats":
+        print("kernel,calls,total_ms,avg_us,min_us,max_us,pct")
+        for r in csv.DictReader(open(path)):
+            k = short(r["Name"]) or r["Name"].split("(")[0][-60:]
+            print("%s,%s,%.3f,%.2f,%.2f,%.2f,%s" % (k, r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                     float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
+                                                     float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    else:
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            if k:
+                agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        print("kernel,counter,dispatches,avg_KB,min_KB,max_KB,avg_bytes_raw,avg_bytes_corrected")
+        for (k, c), v in sorted(agg.items()):
+            avg = sum(v) / len(v)
+            corr = avg * 1024 * (2 if c == "FETCH_SIZE" else 1)
+            print("%s,%s,%d,%.1f,%.1f,%.1f,%.0f,%.0f" % (k, c, len(v), avg, min(v), max(v), avg * 1024, corr))
+
+
+if __name__ == "__main__":
+    main()
