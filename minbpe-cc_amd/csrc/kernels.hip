@@ -10,6 +10,12 @@
 //
 // Integer / index work, HBM-bound: no MFMA anywhere.  Everything is exact
 // (integer atomics commute), so repeated runs are bit-identical.
+//
+// The stream kernels are wave-centric: one wave owns one 512-slot tile at a
+// time (8 slots = one 16-byte load per lane), keeps it in registers, finds
+// neighbours with ballots / ds_bpermute instead of LDS staging, and never
+// needs a workgroup barrier.  Waves walk the tiles with a grid stride and
+// prefetch their next tile while working on the current one.
 #include "mbpe_dev.h"
 
 namespace mbpe {
@@ -17,8 +23,13 @@ namespace mbpe {
 namespace {
 
 constexpr int kWave = 64;
+constexpr uint32_t kSent = 0x10000u;   // "nothing in this lane" (not a 16-bit value)
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rlane(uint32_t v, uint32_t uniform_lane) {
+    return __builtin_amdgcn_readlane(v, rfl(uniform_lane));
+}
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     const uint32_t lane = lane_id();
@@ -45,6 +56,14 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
         v = o > v ? o : v;
     }
     return v;
+}
+
+// sum over all lanes of a per-lane count in [0, 8], via ballots (scalar popcounts)
+__device__ __forceinline__ uint32_t wave_sum_le8(uint32_t v, unsigned long long lane_mask) {
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) s += __popcll(__ballot(v > k) & lane_mask);
+    return s;
 }
 
 // ---- pair table device ops ------------------------------------------------
@@ -108,32 +127,39 @@ __global__ void k_fill_u16(uint16_t *p, uint64_t n, uint16_t v) {
 // ---- pair-count scan ------------------------------------------------------
 // One workgroup per CU keeps a private histogram of all 65,536 byte pairs in
 // LDS as packed 16-bit counters (128 KiB of the CU's 160 KiB).  Each lane
-// reads 16 corpus bytes with one 16-byte load and issues 16 LDS atomics.
+// reads 16 corpus bytes with one 16-byte load (the next iteration's load is
+// issued before the current one is consumed) and issues 16 LDS atomics.
 //
-// Exactness of the 16-bit counters: an epoch is two iterations of the
-// 1024-thread workgroup = 32,768 increments.  A lane that sees a counter at
-// or above 0x4000 in the value returned by its atomic raises a flag; at the
+// bin = first | second << 8 (the little-endian 16-bit value at the pair's
+// offset); counter word = bin & 0x7FFF, half = bin >> 15.
+//
+// Exactness of the 16-bit counters: an epoch is three iterations of the
+// 1024-thread workgroup = 49,152 increments.  A lane that sees a counter at
+// or above 0x2000 in the value returned by its atomic raises a flag; at the
 // epoch boundary a raised flag makes the workgroup drain every counter
-// >= 0x4000 to the global table.  So every counter is <= 0x4000 when an
-// epoch starts and gains at most 0x8000 inside it: it never wraps.
+// >= 0x2000 to the global table.  So every counter is <= 0x2000 when an
+// epoch starts and gains at most 0xC000 inside it: it never wraps.
 constexpr int kPcThreads = 1024;
 constexpr int kPcWords = 32768;            // 2 counters per word
-constexpr uint32_t kPcFlagAt = 0x4000u;
+constexpr uint32_t kPcHotBits = 0xE000u;   // counter >= 0x2000
+constexpr int kPcEpochIters = 3;
 
-__device__ __forceinline__ uint32_t pc_table_index(uint32_t le_bin) {
-    // LDS bins are indexed by the little-endian 16-bit load (first | second<<8);
-    // the output table by (first << 8) | second.
-    return ((le_bin & 0xFFu) << 8) | (le_bin >> 8);
+__device__ __forceinline__ uint32_t pc_table_index(uint32_t bin) {
+    return ((bin & 0xFFu) << 8) | (bin >> 8);   // -> (first << 8) | second
 }
 
-__device__ __forceinline__ void pc_drain(uint32_t *hist, uint32_t *bp, uint32_t threshold) {
-    for (uint32_t w = threadIdx.x; w < (uint32_t)kPcWords; w += kPcThreads) {
-        uint32_t v = hist[w];
-        uint32_t lo = v & 0xFFFFu, hi = v >> 16;
-        uint32_t nv = v;
-        if (lo >= threshold && lo) { atomicAdd(&bp[pc_table_index(w)], lo); nv &= 0xFFFF0000u; }
-        if (hi >= threshold && hi) { atomicAdd(&bp[pc_table_index(w + kPcWords)], hi); nv &= 0x0000FFFFu; }
-        if (nv != v) hist[w] = nv;
+__device__ __forceinline__ void pc_drain(uint32_t *hist, uint32_t *bp, uint32_t hot_bits) {
+    // lanes walk consecutive OUTPUT indices so the global atomics of a wave
+    // are contiguous (the LDS reads are bank-conflicted, but this is rare)
+    for (uint32_t o = threadIdx.x; o < 65536u; o += kPcThreads) {
+        const uint32_t bin = ((o & 0xFFu) << 8) | (o >> 8);
+        const uint32_t w = bin & 0x7FFFu, sh = (bin >> 15) * 16;
+        const uint32_t v = hist[w];
+        const uint32_t c = (v >> sh) & 0xFFFFu;
+        if (c && (hot_bits == 0 || (c & hot_bits))) {
+            atomicAdd(&bp[o], c);
+            atomicAnd(&hist[w], ~(0xFFFFu << sh));
+        }
     }
 }
 
@@ -153,70 +179,80 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__r
     uint64_t v_end = v_begin + per;
     if (v_end > n_vec) v_end = n_vec;
     const uint32_t lane = lane_id();
+    const uint64_t n_full = n / 16;            // vectors with all 16 bytes inside the text
+
+    // software pipeline: q/e/xb hold the vector of the NEXT iteration
+    uint4 q = make_uint4(0, 0, 0, 0);
+    uint32_t e = 0, xb = 0;
+    auto issue = [&](uint64_t base) {
+        const uint64_t vec = base + threadIdx.x;
+        q = make_uint4(0, 0, 0, 0);
+        e = 0;
+        xb = 0;
+        if (vec < v_end) {
+            const uint64_t byte0 = vec * 16;
+            if (vec < n_full) {
+                q = *reinterpret_cast<const uint4 *>(text + byte0);
+            } else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint64_t i = byte0; i < n; ++i) w[(i - byte0) >> 2] |= (uint32_t)text[i] << (8 * ((i - byte0) & 3));
+                q = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            if (MASKED) e = reinterpret_cast<const uint16_t *>(endmask)[vec];
+            if (lane == kWave - 1 && byte0 + 16 < n) xb = text[byte0 + 16];
+        }
+    };
+    if (v_begin < v_end) issue(v_begin);
 
     int epoch_iter = 0;
     for (uint64_t base = v_begin; base < v_end; base += kPcThreads) {
+        const uint4 cq = q;
+        const uint32_t ce = e, cxb = xb;
+        if (base + kPcThreads < v_end) issue(base + kPcThreads);
+
         const uint64_t vec = base + threadIdx.x;
         const uint64_t byte0 = vec * 16;
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (vec < v_end) {
-            if (byte0 + 16 <= n) {
-                uint4 q = *reinterpret_cast<const uint4 *>(text + byte0);
-                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-            } else {
-                for (uint64_t i = byte0; i < n; ++i)
-                    w[(i - byte0) >> 2] |= (uint32_t)text[i] << (8 * ((i - byte0) & 3));
-            }
-        }
         // first byte of the next lane's vector = second byte of my last pair
-        uint32_t nb = __shfl_down(w[0], 1, kWave) & 0xFFu;
-        if (lane == kWave - 1 && byte0 + 16 < n && vec < v_end) nb = text[byte0 + 16];
-        uint32_t ends = 0;
-        if (MASKED && vec < v_end && byte0 < n) ends = reinterpret_cast<const uint16_t *>(endmask)[vec];
-        // number of pairs that start in this vector
+        uint32_t nb = __shfl_down(cq.x, 1, kWave) & 0xFFu;
+        if (lane == kWave - 1) nb = cxb;
+        // pairs that start in this vector: byte0 .. min(byte0+15, n-2)
         uint32_t n_pairs = 0;
         if (vec < v_end && byte0 + 1 < n) {
-            uint64_t rem = n - 1 - byte0;   // pairs starting at byte0 .. n-2
+            const uint64_t rem = n - 1 - byte0;
             n_pairs = rem < 16 ? (uint32_t)rem : 16u;
         }
-        uint32_t olds[16];
-        uint32_t bins[16];
+        uint32_t valid = n_pairs >= 16 ? 0xFFFFu : ((1u << n_pairs) - 1u);
+        if (MASKED) valid &= ~ce;
+        const uint32_t w[5] = {cq.x, cq.y, cq.z, cq.w, nb};
+        uint32_t hot = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            uint32_t cur = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            uint32_t nxt = (i < 15) ? ((w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu) : nb;
-            uint32_t bin = cur | (nxt << 8);
-            bool valid = (uint32_t)i < n_pairs && !(MASKED && ((ends >> i) & 1u));
-            bins[i] = valid ? bin : 0xFFFFFFFFu;
-            if (valid) {
-                uint32_t inc = (bin & 0x8000u) ? 0x10000u : 1u;
-                olds[i] = atomicAdd(&hist[bin & 0x7FFFu], inc);
-            } else {
-                olds[i] = 0;
-            }
-        }
-        bool hot = false;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (bins[i] != 0xFFFFFFFFu) {
-                uint32_t half = (bins[i] & 0x8000u) ? (olds[i] >> 16) : (olds[i] & 0xFFFFu);
-                hot |= half >= kPcFlagAt;
+            const int wi = i >> 2, sh = 8 * (i & 3);
+            uint32_t bin;
+            if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
+            else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
+            const uint32_t half = bin >> 15;
+            const uint32_t inc = half ? 0x10000u : 1u;
+            if ((valid >> i) & 1u) {
+                const uint32_t old = atomicAdd(&hist[bin & 0x7FFFu], inc);
+                hot |= old & (inc * kPcHotBits);
             }
         }
         if (hot) *flag = 1;
-        if (++epoch_iter == 2) {
+        if (++epoch_iter == kPcEpochIters) {
             epoch_iter = 0;
             __syncthreads();
-            if (*flag) {            // uniform: read after the barrier
-                __syncthreads();
-                pc_drain(hist, bp, kPcFlagAt);
-                if (threadIdx.x == 0) *flag = 0;
-            }
+            const uint32_t f = *flag;      // uniform: read between two barriers
             __syncthreads();
+            if (f) {
+                pc_drain(hist, bp, kPcHotBits);
+                if (threadIdx.x == 0) *flag = 0;
+                __syncthreads();
+            }
         }
     }
     __syncthreads();
-    pc_drain(hist, bp, 1);
+    pc_drain(hist, bp, 0);
 }
 
 // ---- widen: byte corpus -> 16-bit slot stream ------------------------------
@@ -258,92 +294,128 @@ __global__ void k_widen(const uint8_t *__restrict__ text, uint64_t n, const uint
     }
 }
 
-// ---- tile helpers -----------------------------------------------------------
+// ---- wave-level tile helpers ---------------------------------------------------
 
-// Loads the tile's slots, squeezes the live ones into dense[2 .. 2+n_live)
-// (LDS) and returns this thread's first dense index and live count.
-struct TileLoad {
-    uint32_t s[kSlotsPerThread];
-    uint32_t first;    // dense index of this thread's first live slot
-    uint32_t count;    // live slots of this thread
-    uint32_t n_live;   // live slots of the tile
-};
-
-__device__ __forceinline__ TileLoad tile_load_dense(const uint16_t *tok, uint32_t tile, uint16_t *dense,
-                                                    uint32_t *wsum) {
-    TileLoad r;
-    const uint4 q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kMergeThreads + threadIdx.x];
-    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int j = 0; j < kSlotsPerThread; ++j) {
-        r.s[j] = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-        cnt += r.s[j] != kHole;
-    }
-    const uint32_t incl = wave_incl_scan(cnt);
-    const uint32_t wid = threadIdx.x / kWave;
-    if (lane_id() == kWave - 1) wsum[wid] = incl;
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < kMergeThreads / kWave; ++k) {
-        uint32_t v = wsum[k];
-        if ((uint32_t)k < wid) base += v;
-        total += v;
-    }
-    r.first = base + incl - cnt;
-    r.count = cnt;
-    r.n_live = total;
-    uint32_t o = r.first + 2;
-#pragma unroll
-    for (int j = 0; j < kSlotsPerThread; ++j)
-        if (r.s[j] != kHole) dense[o++] = (uint16_t)r.s[j];
-    return r;
+__device__ __forceinline__ void unpack8(const uint4 &q, uint32_t s[8]) {
+    s[0] = q.x & 0xFFFFu; s[1] = q.x >> 16;
+    s[2] = q.y & 0xFFFFu; s[3] = q.y >> 16;
+    s[4] = q.z & 0xFFFFu; s[5] = q.z >> 16;
+    s[6] = q.w & 0xFFFFu; s[7] = q.w >> 16;
 }
 
-// Summary of the live tokens in d[0..n) where kHole entries are skipped.
-__device__ TileSum summarize_lds(const uint16_t *d, int n, uint32_t n_live) {
-    TileSum s;
-    s.head0 = s.head1 = s.tail0 = s.tail1 = (uint16_t)kHole;
-    s.n_live = (uint16_t)n_live;
-    s.tail_run = 0;
-    s.pad0 = s.pad1 = 0;
-    int found = 0;
-    for (int i = 0; i < n && found < 2; ++i) {
-        uint16_t v = d[i];
-        if (v == kHole) continue;
-        if (found == 0) s.head0 = v; else s.head1 = v;
-        ++found;
-    }
-    found = 0;
-    uint32_t run = 0;
-    bool counting = true;
-    for (int i = n - 1; i >= 0 && (found < 2 || counting); --i) {
-        uint16_t v = d[i];
-        if (v == kHole) continue;
-        if (found == 0) { s.tail0 = v; run = 1; }
-        else {
-            if (found == 1) s.tail1 = v;
-            if (counting) { if (v == s.tail0) ++run; else counting = false; }
+__device__ __forceinline__ uint4 pack8(const uint32_t s[8]) {
+    return make_uint4(s[0] | (s[1] << 16), s[2] | (s[3] << 16), s[4] | (s[5] << 16), s[6] | (s[7] << 16));
+}
+
+__device__ __forceinline__ uint4 sum_to_u4(uint32_t head0, uint32_t head1, uint32_t tail1, uint32_t tail0,
+                                           uint32_t n_live, uint32_t tail_run) {
+    return make_uint4(head0 | (head1 << 16), tail1 | (tail0 << 16), n_live | (tail_run << 16), 0u);
+}
+
+// The summary of one tile from its (new) slot values, computed by the whole
+// wave; the result is uniform.  v[j] == kHole marks a dead slot.
+__device__ __forceinline__ uint4 wave_summary(const uint32_t v[8]) {
+    uint32_t cnt = 0, f1 = kSent, f2 = kSent, l1 = kSent, l2 = kSent;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (v[j] != kHole) {
+            if (cnt == 0) f1 = v[j]; else if (cnt == 1) f2 = v[j];
+            l2 = l1; l1 = v[j];
+            ++cnt;
         }
-        ++found;
     }
-    s.tail_run = (uint16_t)run;
-    return s;
+    const unsigned long long mh = __ballot(cnt > 0);
+    if (!mh) return sum_to_u4(kHole, kHole, kHole, kHole, 0, 0);
+    const uint32_t lowlane = __builtin_ctzll(mh), highlane = 63 - __builtin_clzll(mh);
+    uint32_t head0 = rlane(f1, lowlane), head1 = rlane(f2, lowlane);
+    if (head1 == kSent) {
+        const unsigned long long m2 = mh & ~(1ull << lowlane);
+        head1 = m2 ? rlane(f1, __builtin_ctzll(m2)) : kHole;
+    }
+    uint32_t tail0 = rlane(l1, highlane), tail1 = rlane(l2, highlane);
+    if (tail1 == kSent) {
+        const unsigned long long m2 = mh & ~(1ull << highlane);
+        tail1 = m2 ? rlane(l1, 63 - __builtin_clzll(m2)) : kHole;
+    }
+    const uint32_t n_live = wave_sum_le8(cnt, ~0ull);
+    // trailing run of tokens equal (raw) to tail0
+    uint32_t trail = 0;
+    bool stop = false;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        if (v[j] != kHole) {
+            if (!stop && v[j] == tail0) ++trail; else stop = true;
+        }
+    }
+    const unsigned long long brk = __ballot(cnt > 0 && stop);
+    uint32_t run;
+    if (!brk) {
+        run = n_live;
+    } else {
+        const uint32_t B = 63 - __builtin_clzll(brk);
+        const unsigned long long above = B == 63 ? 0ull : ~((2ull << B) - 1ull);
+        run = rlane(trail, B) + wave_sum_le8(cnt, above);
+    }
+    return sum_to_u4(head0, head1, tail1, tail0, n_live, run);
+}
+
+struct Halo { uint32_t p2, p1, n1, n2; };
+
+// Neighbour tokens of a tile when the adjacent summaries cannot answer
+// directly (first / last tile, or a neighbour with fewer than two live
+// tokens): walk the summaries, then the rank edges of a multi-GPU run.
+__device__ Halo halo_slow(const TileSum *sin, uint32_t n_tiles, uint32_t tile, const RankEdge *le,
+                          const RankEdge *re) {
+    Halo h;
+    h.p1 = h.p2 = h.n1 = h.n2 = kHole;
+    int need = 2;
+    for (int64_t j = (int64_t)tile - 1; need && j >= -1; --j) {
+        uint32_t nl, t0, t1;
+        if (j >= 0) { TileSum s = sin[j]; nl = s.n_live; t0 = s.tail0; t1 = s.tail1; }
+        else if (le) { t0 = le->tail0; t1 = le->tail1; nl = t0 == kHole ? 0 : (t1 == kHole ? 1 : 2); }
+        else break;
+        if (nl == 0) continue;
+        if (need == 2) { h.p1 = t0; need = 1; if (nl >= 2) { h.p2 = t1; need = 0; } }
+        else { h.p2 = t0; need = 0; }
+    }
+    need = 2;
+    for (int64_t j = (int64_t)tile + 1; need && j <= (int64_t)n_tiles; ++j) {
+        uint32_t nl, t0, t1;
+        if (j < (int64_t)n_tiles) { TileSum s = sin[j]; nl = s.n_live; t0 = s.head0; t1 = s.head1; }
+        else if (re) { t0 = re->head0; t1 = re->head1; nl = t0 == kHole ? 0 : (t1 == kHole ? 1 : 2); }
+        else break;
+        if (nl == 0) continue;
+        if (need == 2) { h.n1 = t0; need = 1; if (nl >= 2) { h.n2 = t1; need = 0; } }
+        else { h.n2 = t0; need = 0; }
+    }
+    return h;
+}
+
+// number of tokens equal to raw `a` immediately before `tile` (a == b merges)
+__device__ unsigned long long run_before_slow(const TileSum *sin, uint32_t tile, uint32_t a, const RankEdge *le) {
+    unsigned long long rb = 0;
+    int64_t j = (int64_t)tile - 1;
+    for (; j >= 0; --j) {
+        TileSum s = sin[j];
+        if (s.n_live == 0) continue;
+        if (s.tail0 != a) return rb;
+        rb += s.tail_run;
+        if (s.tail_run != s.n_live) return rb;
+    }
+    if (le && le->tail0 == a) rb += ((unsigned long long)le->tail_run_hi << 32) | le->tail_run_lo;
+    return rb;
 }
 
 __global__ __launch_bounds__(kMergeThreads) void k_summarize(const uint16_t *__restrict__ tok,
-                                                             TileSum *__restrict__ sums, uint32_t n_tiles,
-                                                             DevCtl *ctl, int set_n_live) {
-    __shared__ uint16_t dense[kTile + 4];
-    __shared__ uint32_t wsum[kMergeThreads / kWave];
-    const uint32_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    TileLoad tl = tile_load_dense(tok, tile, dense, wsum);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        sums[tile] = summarize_lds(dense + 2, (int)tl.n_live, tl.n_live);
-        if (set_n_live) atomicAdd(&ctl->n_live, (unsigned long long)tl.n_live);
+                                                             TileSum *__restrict__ sums, uint32_t n_tiles) {
+    const uint32_t waves_per_block = kMergeThreads / kWave;
+    const uint32_t n_waves = gridDim.x * waves_per_block;
+    for (uint32_t tile = blockIdx.x * waves_per_block + threadIdx.x / kWave; tile < n_tiles; tile += n_waves) {
+        const uint4 q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kWave + lane_id()];
+        uint32_t s[8];
+        unpack8(q, s);
+        const uint4 sum = wave_summary(s);
+        if (lane_id() == 0) reinterpret_cast<uint4 *>(sums)[tile] = sum;
     }
 }
 
@@ -395,7 +467,7 @@ __global__ void k_table_rehash(PairTable t, DevCtl *ctl) {
 }
 
 // ---- merge pass ------------------------------------------------------------------
-// One workgroup per tile, in place.  For the chosen pair (a,b) -> X
+// In place, one wave per tile.  For the chosen pair (a,b) -> X
 // (merge_incremental, Tokenizer.h:202-306):
 //   - the slot holding `a` of a match becomes X (keeping b's chunk-end flag),
 //     the slot holding `b` becomes a hole                          (:236-237)
@@ -407,51 +479,27 @@ __global__ void k_table_rehash(PairTable t, DevCtl *ctl) {
 //     which is the reference's sequential result: its transient (X,a)+1/-1
 //     on touching matches cancels (SURVEY.md 8-S rule 3).
 // Neighbour tokens across the tile edge come from the tile summaries of the
-// previous pass, never from the neighbour's slots.
+// previous pass (ping-pong sin -> sout), never from the neighbour's slots, so
+// rewriting in place cannot race with a neighbour's reads.
+//
+// Most tiles hold no match: they are recognised from the 8 slots per lane
+// with a backward "next live token" chain and one ballot, and only cost the
+// 16-byte load plus the 16-byte summary copy.
 
-struct Halo { uint32_t p2, p1, n1, n2, run_before; };
+struct TileIn {
+    uint4 q;    // this lane's 8 slots
+    uint4 sm;   // lanes 0,1,2: summaries of tile-1, tile, tile+1
+};
 
-__device__ Halo tile_halo(const TileSum *sin, uint32_t n_tiles, uint32_t tile, uint32_t a, bool same,
-                          const RankEdge *le, const RankEdge *re) {
-    Halo h;
-    h.p1 = h.p2 = h.n1 = h.n2 = kHole;
-    h.run_before = 0;
-    int need = 2;
-    for (int64_t j = (int64_t)tile - 1; need && j >= -1; --j) {
-        uint32_t nl, t0, t1;
-        if (j >= 0) { TileSum s = sin[j]; nl = s.n_live; t0 = s.tail0; t1 = s.tail1; }
-        else if (le) { nl = (le->n_live_lo | le->n_live_hi) ? 2 : 0; t0 = le->tail0; t1 = le->tail1; if (t0 == kHole) nl = 0; else if (t1 == kHole) nl = 1; }
-        else break;
-        if (nl == 0) continue;
-        if (need == 2) { h.p1 = t0; need = 1; if (nl >= 2) { h.p2 = t1; need = 0; } }
-        else { h.p2 = t0; need = 0; }
-    }
-    need = 2;
-    for (int64_t j = (int64_t)tile + 1; need && j <= (int64_t)n_tiles; ++j) {
-        uint32_t nl, t0, t1;
-        if (j < (int64_t)n_tiles) { TileSum s = sin[j]; nl = s.n_live; t0 = s.head0; t1 = s.head1; }
-        else if (re) { t0 = re->head0; t1 = re->head1; nl = t0 == kHole ? 0 : (t1 == kHole ? 1 : 2); }
-        else break;
-        if (nl == 0) continue;
-        if (need == 2) { h.n1 = t0; need = 1; if (nl >= 2) { h.n2 = t1; need = 0; } }
-        else { h.n2 = t0; need = 0; }
-    }
-    if (same) {
-        // tokens equal to raw `a` immediately before this tile
-        uint64_t rb = 0;
-        int64_t j = (int64_t)tile - 1;
-        for (; j >= 0; --j) {
-            TileSum s = sin[j];
-            if (s.n_live == 0) continue;
-            if (s.tail0 != a) break;
-            rb += s.tail_run;
-            if (s.tail_run != s.n_live) break;
-        }
-        if (j < 0 && le && le->tail0 == a)
-            rb += ((uint64_t)le->tail_run_hi << 32) | le->tail_run_lo;
-        h.run_before = (uint32_t)(rb & 1u) | ((rb >= 2) ? 2u : 0u);   // parity + ">=2" is all that is used
-    }
-    return h;
+__device__ __forceinline__ TileIn tile_issue(const uint16_t *tok, const TileSum *sin, uint32_t n_tiles,
+                                             uint32_t tile) {
+    TileIn t;
+    const uint32_t lane = lane_id();
+    t.q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kWave + lane];
+    t.sm = make_uint4(0, 0, 0, 0);
+    const int64_t j = (int64_t)tile - 1 + lane;
+    if (lane < 3 && j >= 0 && j < (int64_t)n_tiles) t.sm = reinterpret_cast<const uint4 *>(sin)[j];
+    return t;
 }
 
 __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ tok,
@@ -461,120 +509,209 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
                                                          uint32_t X, uint32_t endbit, uint32_t *L,
                                                          uint32_t *R, DevCtl *ctl, const RankEdge *le,
                                                          const RankEdge *re) {
-    __shared__ uint16_t dense[kTile + 4];
-    __shared__ uint16_t newd[kTile];
-    __shared__ uint32_t wsum[kMergeThreads / kWave];
-    __shared__ uint32_t sh[8];   // 0: removed, 1: m, 2: adj, 3: changed, 4: run_before
-    const uint32_t tile = blockIdx.x;
+    const uint32_t lane = lane_id();
+    const uint32_t waves_per_block = kMergeThreads / kWave;
+    const uint32_t n_waves = gridDim.x * waves_per_block;
+    uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     if (tile >= n_tiles) return;
-    const TileSum me = sin[tile];
+
     const unsigned long long best = *best_ptr;
-    if ((best >> 32) == 0 || me.n_live < 1) {   // nothing can match (count 0) or empty tile
-        if (threadIdx.x == 0) sout[tile] = me;
+    if ((best >> 32) == 0) {
+        // count 0 (or no pair at all): nothing matches; keep the summaries valid
+        for (; tile < n_tiles; tile += n_waves)
+            if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = reinterpret_cast<const uint4 *>(sin)[tile];
         return;
     }
     const uint32_t key = ~(uint32_t)best;
     const uint32_t a = key >> 16, b = key & 0xFFFFu;
     const bool same = a == b;
     const uint32_t idmask = endbit ? 0x7FFFu : 0xFFFFu;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
 
-    if (threadIdx.x < 8) sh[threadIdx.x] = 0;
-    TileLoad tl = tile_load_dense(tok, tile, dense, wsum);   // contains a barrier (after sh init)
-    if (threadIdx.x == 0) {
-        Halo h = tile_halo(sin, n_tiles, tile, a, same, le, re);
-        dense[0] = (uint16_t)h.p2;
-        dense[1] = (uint16_t)h.p1;
-        dense[2 + tl.n_live] = (uint16_t)h.n1;
-        dense[3 + tl.n_live] = (uint16_t)h.n2;
-        sh[4] = h.run_before;
-    }
-    __syncthreads();
+    uint32_t wave_m = 0, wave_adj = 0;   // lane-local partial sums, reduced once at the end
 
-    uint32_t my_m = 0, my_adj = 0, my_removed = 0;
-    bool changed = false;
-    {
-        uint32_t i = tl.first;          // index among the tile's live tokens
-        uint32_t run = 0;               // consecutive raw-a tokens right before i (same only)
-        bool run_valid = false;
-        uint32_t run_ge2 = 0;
+    TileIn cur = tile_issue(tok, sin, n_tiles, tile);
+    for (;;) {
+        const uint32_t next_tile = tile + n_waves;
+        const bool has_next = next_tile < n_tiles;
+        TileIn nxt;
+        if (has_next) nxt = tile_issue(tok, sin, n_tiles, next_tile);
+
+        // ---- this tile -------------------------------------------------------
+        const uint32_t me_nlive = rlane(cur.sm.z, 1) & 0xFFFFu;
+        bool copy_summary = true;
+        if (me_nlive != 0) {
+            uint32_t s[8];
+            unpack8(cur.q, s);
+            // neighbours' edge tokens
+            Halo h;
+            {
+                const uint32_t pw1 = rlane(cur.sm.y, 0), pw2 = rlane(cur.sm.z, 0);
+                const uint32_t nw0 = rlane(cur.sm.x, 2), nw2 = rlane(cur.sm.z, 2);
+                const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
+                if (fast) {
+                    h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
+                    h.n1 = nw0 & 0xFFFFu; h.n2 = nw0 >> 16;
+                } else {
+                    h = halo_slow(sin, n_tiles, tile, le, re);
+                }
+            }
+            // next live token of every slot (backward chain inside the lane, then
+            // the first live token of the following lanes / the next tile)
+            uint32_t n1v[8];
+            uint32_t nx = kSent;
 #pragma unroll
-        for (int j = 0; j < kSlotsPerThread; ++j) {
-            const uint32_t self = tl.s[j];
-            if (self == kHole) continue;
-            const uint32_t p2 = dense[i], p1 = dense[i + 1], n1 = dense[i + 3], n2 = dense[i + 4];
-            bool amatch, bmatch;
-            bool prev_adjacent;     // the two tokens before `self` formed a match
-            if (!same) {
-                amatch = (self == a) && ((n1 & idmask) == b);
-                bmatch = ((self & idmask) == b) && (p1 == a);
-                prev_adjacent = (p1 == b) && (p2 == a);
-            } else {
-                amatch = bmatch = prev_adjacent = false;
-                if ((self & idmask) == a) {
-                    if (!run_valid) {
-                        // walk back over the live tokens of this tile, then into the summaries
-                        run = 0;
-                        int64_t k = (int64_t)i - 1;
-                        while (k >= 0 && dense[2 + k] == a) { ++run; --k; }
-                        run_ge2 = run >= 2;
-                        if (k < 0) { uint32_t rb = sh[4]; run += rb & 1u; run_ge2 |= (rb >> 1) | (run >= 2); }
-                        run_valid = true;
+            for (int j = 7; j >= 0; --j) {
+                n1v[j] = nx;
+                if (s[j] != kHole) nx = s[j];
+            }
+            const uint32_t lane_first = nx;            // first live token of this lane
+            const unsigned long long m_live = __ballot(lane_first != kSent);
+            uint32_t src_hi;
+            {
+                const unsigned long long hi = m_live & gt_mask;
+                src_hi = hi ? (uint32_t)__builtin_ctzll(hi) : lane;
+                const uint32_t nf = __shfl(lane_first, src_hi, kWave);
+                const uint32_t n1_in = hi ? nf : h.n1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (n1v[j] == kSent) n1v[j] = n1_in;
+            }
+            bool cand = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cand |= (s[j] == a) && ((n1v[j] & idmask) == b);
+            const bool work = __ballot(cand) != 0ull || h.p1 == a;
+
+            if (work) {
+                // ---- full path: neighbours two deep, decisions, deltas, rewrite ----
+                uint32_t cnt = 0, f2 = kSent, l1 = kSent, l2 = kSent;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (s[j] != kHole) {
+                        if (cnt == 1) f2 = s[j];
+                        l2 = l1; l1 = s[j];
+                        ++cnt;
                     }
-                    const bool odd = run & 1u;
-                    amatch = (self == a) && !odd && ((n1 & idmask) == a);
-                    bmatch = odd;
-                    prev_adjacent = !odd && run_ge2;
+                }
+                // tokens before this lane
+                uint32_t p1_in, p2_in;
+                {
+                    const unsigned long long lo = m_live & lt_mask;
+                    const uint32_t src1 = lo ? 63u - (uint32_t)__builtin_clzll(lo) : lane;
+                    const uint32_t sl1 = __shfl(l1, src1, kWave), sl2 = __shfl(l2, src1, kWave);
+                    const unsigned long long lo2 = lo & ~(1ull << src1);
+                    const uint32_t src2 = lo2 ? 63u - (uint32_t)__builtin_clzll(lo2) : lane;
+                    const uint32_t tl1 = __shfl(l1, src2, kWave);
+                    p1_in = lo ? sl1 : h.p1;
+                    p2_in = lo ? (sl2 != kSent ? sl2 : (lo2 ? tl1 : h.p1)) : h.p2;
+                }
+                // second token after this lane
+                uint32_t n1_in, n2_in;
+                {
+                    const unsigned long long hi = m_live & gt_mask;
+                    const uint32_t sf1 = __shfl(lane_first, src_hi, kWave), sf2 = __shfl(f2, src_hi, kWave);
+                    const unsigned long long hi2 = hi & ~(1ull << src_hi);
+                    const uint32_t src2 = hi2 ? (uint32_t)__builtin_ctzll(hi2) : lane;
+                    const uint32_t tf1 = __shfl(lane_first, src2, kWave);
+                    n1_in = hi ? sf1 : h.n1;
+                    n2_in = hi ? (sf2 != kSent ? sf2 : (hi2 ? tf1 : h.n1)) : h.n2;
+                }
+                uint32_t n2v[8];
+                {
+                    uint32_t x1 = n1_in, x2 = n2_in;
+#pragma unroll
+                    for (int j = 7; j >= 0; --j) {
+                        n2v[j] = x2;
+                        if (s[j] != kHole) { x2 = x1; x1 = s[j]; }
+                    }
+                }
+                // a == b: tokens equal to raw `a` immediately before this lane's first slot
+                uint32_t run = 0;
+                if (same) {
+                    bool all_a = true;
+                    uint32_t trail = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (s[j] != kHole) {
+                            if (s[j] == a) ++trail; else { trail = 0; all_a = false; }
+                        }
+                    }
+                    // inclusive scan of (all_a, trail): R after L -> R.all ? (L.all, L.trail + R.trail) : R
+                    uint32_t sa = all_a ? 1u : 0u, st = trail;
+#pragma unroll
+                    for (int d = 1; d < kWave; d <<= 1) {
+                        const uint32_t oa = __shfl_up(sa, d, kWave), ot = __shfl_up(st, d, kWave);
+                        if (lane >= (uint32_t)d && sa) { st += ot; sa = oa; }
+                    }
+                    uint32_t ea = __shfl_up(sa, 1, kWave), et = __shfl_up(st, 1, kWave);
+                    if (lane == 0) { ea = 1; et = 0; }
+                    // the run reaches the tile start for the lanes with ea set
+                    unsigned long long rb = 0;
+                    if (__ballot(ea && cnt > 0) != 0ull && h.p1 == a) rb = run_before_slow(sin, tile, a, le);
+                    const uint32_t rb_small = (uint32_t)(rb & 1ull) | (rb >= 2 ? 2u : 0u);
+                    run = ea ? et + rb_small : et;   // parity and ">= 2" are all that is used below
+                }
+
+                uint32_t my_m = 0, my_adj = 0;
+                bool changed = false;
+                uint32_t p1 = p1_in, p2 = p2_in;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t self = s[j];
+                    if (self == kHole) continue;
+                    const uint32_t n1 = n1v[j], n2 = n2v[j];
+                    bool amatch, bmatch, prev_adjacent;
+                    if (!same) {
+                        amatch = (self == a) && ((n1 & idmask) == b);
+                        bmatch = ((self & idmask) == b) && (p1 == a);
+                        prev_adjacent = (p1 == b) && (p2 == a);
+                    } else {
+                        const bool is_a = (self & idmask) == a;
+                        const bool odd = run & 1u;
+                        amatch = (self == a) && !odd && ((n1 & idmask) == a);
+                        bmatch = is_a && odd;
+                        prev_adjacent = !odd && run >= 2;
+                        run = (self == a) ? run + 1 : 0;
+                    }
+                    uint32_t nv = self;
+                    if (amatch) {
+                        nv = X | (n1 & endbit);
+                        ++my_m;
+                        if (p1 != kHole && !(p1 & endbit)) {
+                            if (prev_adjacent) ++my_adj;
+                            else atomicAdd(&L[p1], 1u);
+                        }
+                    } else if (bmatch) {
+                        nv = kHole;
+                        if (!(self & endbit) && n1 != kHole) {
+                            const bool next_adjacent = (n1 == a) && ((n2 & idmask) == b);
+                            if (!next_adjacent) atomicAdd(&R[n1 & idmask], 1u);
+                        }
+                    }
+                    p2 = p1; p1 = self;       // neighbours are the OLD tokens
+                    if (nv != self) { changed = true; s[j] = nv; }
+                }
+                if (changed)
+                    reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
+                wave_m += my_m;
+                wave_adj += my_adj;
+                if (__ballot(changed) != 0ull) {
+                    const uint4 ns = wave_summary(s);
+                    if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
+                    copy_summary = false;
                 }
             }
-            // maintain the run for the next live token of this thread
-            if (same) {
-                if (self == a) { if (run_valid) { ++run; run_ge2 = run >= 2 || run_ge2; } }
-                else { run = 0; run_ge2 = 0; run_valid = true; }
-            }
-            uint32_t nv = self;
-            if (amatch) {
-                nv = X | (n1 & endbit);
-                ++my_m;
-                if (p1 != kHole && !(p1 & endbit)) {
-                    if (prev_adjacent) ++my_adj;
-                    else atomicAdd(&L[p1], 1u);
-                }
-            } else if (bmatch) {
-                nv = kHole;
-                ++my_removed;
-                if (!(self & endbit) && n1 != kHole) {
-                    const bool next_adjacent = (n1 == a) && ((n2 & idmask) == b);
-                    if (!next_adjacent) atomicAdd(&R[n1 & idmask], 1u);
-                }
-            }
-            if (nv != self) { changed = true; tl.s[j] = nv; }
-            newd[i] = (uint16_t)nv;
-            ++i;
         }
+        if (copy_summary && lane == 1) reinterpret_cast<uint4 *>(sout)[tile] = cur.sm;
+
+        if (!has_next) break;
+        tile = next_tile;
+        cur = nxt;
     }
-    if (changed) {
-        uint4 q;
-        q.x = tl.s[0] | (tl.s[1] << 16);
-        q.y = tl.s[2] | (tl.s[3] << 16);
-        q.z = tl.s[4] | (tl.s[5] << 16);
-        q.w = tl.s[6] | (tl.s[7] << 16);
-        reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kMergeThreads + threadIdx.x] = q;
-    }
-    const uint32_t wm = wave_sum(my_m), wa = wave_sum(my_adj), wr = wave_sum(my_removed);
-    if (lane_id() == 0 && (wm | wa | wr)) {
-        atomicAdd(&sh[0], wr);
-        atomicAdd(&sh[1], wm);
-        atomicAdd(&sh[2], wa);
-    }
-    const int any_changed = __syncthreads_or(changed);
-    if (threadIdx.x == 0) {
-        if (!any_changed) {
-            sout[tile] = me;
-        } else {
-            sout[tile] = summarize_lds(newd, (int)tl.n_live, tl.n_live - sh[0]);
-            if (sh[1]) atomicAdd(&ctl->m, sh[1]);
-            if (sh[2]) atomicAdd(&ctl->adj, sh[2]);
-        }
+    const uint32_t tm = wave_sum(wave_m), ta = wave_sum(wave_adj);
+    if (lane == 0) {
+        if (tm) atomicAdd(&ctl->m, tm);
+        if (ta) atomicAdd(&ctl->adj, ta);
     }
 }
 
@@ -629,7 +766,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_scan(const TileSum *__res
                                                             DevCtl *ctl) {
     __shared__ unsigned long long part[kScanThreads];
     const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
-    const uint32_t lo = threadIdx.x * per;
+    const uint32_t lo = threadIdx.x * per < n_tiles ? threadIdx.x * per : n_tiles;
     const uint32_t hi = lo + per < n_tiles ? lo + per : n_tiles;
     unsigned long long s = 0;
     for (uint32_t i = lo; i < hi; ++i) s += sums[i].n_live;
@@ -649,15 +786,22 @@ __global__ __launch_bounds__(kMergeThreads) void k_compact_scatter(const uint16_
                                                                    const TileSum *__restrict__ sums,
                                                                    const unsigned long long *__restrict__ offsets,
                                                                    uint32_t n_tiles, uint16_t *__restrict__ dst) {
-    __shared__ uint16_t dense[kTile + 4];
-    __shared__ uint32_t wsum[kMergeThreads / kWave];
-    const uint32_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    if (sums[tile].n_live == 0) return;
-    TileLoad tl = tile_load_dense(src, tile, dense, wsum);
-    __syncthreads();
-    const unsigned long long off = offsets[tile];
-    for (uint32_t i = threadIdx.x; i < tl.n_live; i += kMergeThreads) dst[off + i] = dense[2 + i];
+    const uint32_t waves_per_block = kMergeThreads / kWave;
+    const uint32_t n_waves = gridDim.x * waves_per_block;
+    for (uint32_t tile = blockIdx.x * waves_per_block + threadIdx.x / kWave; tile < n_tiles; tile += n_waves) {
+        if (sums[tile].n_live == 0) continue;
+        const uint4 q = reinterpret_cast<const uint4 *>(src)[(uint64_t)tile * kWave + lane_id()];
+        uint32_t s[8];
+        unpack8(q, s);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cnt += s[j] != kHole;
+        const uint32_t excl = wave_incl_scan(cnt) - cnt;
+        uint16_t *o = dst + offsets[tile] + excl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (s[j] != kHole) *o++ = (uint16_t)s[j];
+    }
 }
 
 // ---- rank edge (multi-GPU) ---------------------------------------------------------------
@@ -703,6 +847,17 @@ inline int blocks_for(uint64_t n, int threads, int max_blocks) {
     return (int)b;
 }
 
+// grid for the wave-per-tile kernels: enough waves to fill the chip (8 blocks
+// of 4 waves per CU), fewer when the stream is short
+inline int tile_grid(uint32_t n_tiles, int n_cus) {
+    const uint32_t waves_per_block = kMergeThreads / kWave;
+    uint64_t blocks = ((uint64_t)n_tiles + waves_per_block - 1) / waves_per_block;
+    const uint64_t cap = (uint64_t)(n_cus > 0 ? n_cus : 256) * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
 }  // namespace
 
 // ---- launchers ---------------------------------------------------------------------------
@@ -740,10 +895,9 @@ void launch_widen(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t 
         hipLaunchKernelGGL(k_widen<false>, dim3(blocks), dim3(256), 0, s, text, n, endmask, tok, n_slots_padded);
 }
 
-void launch_summarize(hipStream_t s, const uint16_t *tok, TileSum *sums, uint32_t n_tiles, DevCtl *ctl,
-                      int set_n_live) {
+void launch_summarize(hipStream_t s, const uint16_t *tok, TileSum *sums, uint32_t n_tiles, int n_cus) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(k_summarize, dim3(n_tiles), dim3(kMergeThreads), 0, s, tok, sums, n_tiles, ctl, set_n_live);
+    hipLaunchKernelGGL(k_summarize, dim3(tile_grid(n_tiles, n_cus)), dim3(kMergeThreads), 0, s, tok, sums, n_tiles);
 }
 
 void launch_table_init(hipStream_t s, const uint32_t *bp, PairTable t, DevCtl *ctl) {
@@ -761,10 +915,10 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 
 void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sin, TileSum *sout, uint32_t n_tiles,
                   const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *L, uint32_t *R,
-                  DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge) {
+                  DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(k_merge, dim3(n_tiles), dim3(kMergeThreads), 0, s, tok, sin, sout, n_tiles, best, new_id,
-                       endbit, L, R, ctl, left_edge, right_edge);
+    hipLaunchKernelGGL(k_merge, dim3(tile_grid(n_tiles, n_cus)), dim3(kMergeThreads), 0, s, tok, sin, sout, n_tiles,
+                       best, new_id, endbit, L, R, ctl, left_edge, right_edge);
 }
 
 void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best, uint32_t new_id,
@@ -778,9 +932,10 @@ void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles, unsi
 }
 
 void launch_compact_scatter(hipStream_t s, const uint16_t *src, const TileSum *sums,
-                            const unsigned long long *offsets, uint32_t n_tiles, uint16_t *dst) {
+                            const unsigned long long *offsets, uint32_t n_tiles, uint16_t *dst, int n_cus) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(k_compact_scatter, dim3(n_tiles), dim3(kMergeThreads), 0, s, src, sums, offsets, n_tiles, dst);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(tile_grid(n_tiles, n_cus)), dim3(kMergeThreads), 0, s, src, sums,
+                       offsets, n_tiles, dst);
 }
 
 void launch_rank_edge(hipStream_t s, const TileSum *sums, uint32_t n_tiles, RankEdge *out) {

@@ -17,9 +17,9 @@ namespace mbpe {
 constexpr uint32_t kHole = 0xFFFFu;    // also "no token" in tile summaries
 constexpr uint32_t kEndBit = 0x8000u;  // chunked corpora only
 
-constexpr int kTile = 2048;            // slots per tile (one workgroup)
-constexpr int kMergeThreads = 256;
-constexpr int kSlotsPerThread = kTile / kMergeThreads;  // 8 = one 16-byte load
+constexpr int kTile = 512;             // slots per tile = one wave x 8 slots (one 16-byte load per lane)
+constexpr int kMergeThreads = 256;     // 4 waves per workgroup, each wave walks its own tiles
+constexpr int kSlotsPerLane = 8;
 
 // What a tile exposes to its neighbours; written by the pass that last
 // changed the tile, read (never the neighbour's slots) by the next pass, so
@@ -99,8 +99,7 @@ void launch_widen(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t 
                   uint16_t *tok, uint64_t n_slots_padded);
 
 // recompute every tile summary from the slots
-void launch_summarize(hipStream_t s, const uint16_t *tok, TileSum *sums, uint32_t n_tiles,
-                      DevCtl *ctl, int set_n_live);
+void launch_summarize(hipStream_t s, const uint16_t *tok, TileSum *sums, uint32_t n_tiles, int n_cus);
 
 // dense byte-pair histogram -> pair table
 void launch_table_init(hipStream_t s, const uint32_t *bp, PairTable t, DevCtl *ctl);
@@ -114,7 +113,7 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sin, TileSum *sout,
                   uint32_t n_tiles, const unsigned long long *best, uint32_t new_id,
                   uint32_t endbit, uint32_t *L, uint32_t *R, DevCtl *ctl,
-                  const RankEdge *left_edge, const RankEdge *right_edge);
+                  const RankEdge *left_edge, const RankEdge *right_edge, int n_cus);
 
 // fold the merge's count deltas (L, R, m, adj) into the pair table
 void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best,
@@ -124,7 +123,7 @@ void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long l
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles,
                       unsigned long long *offsets, DevCtl *ctl);
 void launch_compact_scatter(hipStream_t s, const uint16_t *src, const TileSum *sums,
-                            const unsigned long long *offsets, uint32_t n_tiles, uint16_t *dst);
+                            const unsigned long long *offsets, uint32_t n_tiles, uint16_t *dst, int n_cus);
 
 // this rank's RankEdge from its tile summaries
 void launch_rank_edge(hipStream_t s, const TileSum *sums, uint32_t n_tiles, RankEdge *out);

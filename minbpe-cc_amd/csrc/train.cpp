@@ -204,7 +204,7 @@ int do_compact(mbpe_ctx *c) {
     if (!c->n_tiles) return MBPE_OK;
     const int src = c->cur, dst = 1 - c->cur;
     launch_tile_scan(c->stream, c->sums[c->scur], c->n_tiles, c->offsets, c->ctl);
-    launch_compact_scatter(c->stream, c->tok[src], c->sums[c->scur], c->offsets, c->n_tiles, c->tok[dst]);
+    launch_compact_scatter(c->stream, c->tok[src], c->sums[c->scur], c->offsets, c->n_tiles, c->tok[dst], c->n_cus);
     const uint64_t live = c->h_ctl.n_live;
     const uint64_t padded = std::max<uint64_t>(round_up(live, kTile), kTile);
     launch_fill_u16(c->stream, c->tok[dst] + live, padded - live, (uint16_t)kHole);
@@ -212,7 +212,7 @@ int do_compact(mbpe_ctx *c) {
     c->n_slots = padded;
     c->n_tiles = (uint32_t)(padded / kTile);
     c->scur = 0;
-    launch_summarize(c->stream, c->tok[c->cur], c->sums[c->scur], c->n_tiles, c->ctl, 0);
+    launch_summarize(c->stream, c->tok[c->cur], c->sums[c->scur], c->n_tiles, c->n_cus);
     DevCtl patch = c->h_ctl;
     patch.removed_total = 0;
     HIPCHK(hipMemcpyAsync(&c->ctl->removed_total, &patch.removed_total, sizeof(patch.removed_total),
@@ -418,7 +418,12 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(hipMalloc(&c->L, ((size_t)vocab_size * 2 + 8) * 4));
     c->R = c->L + vocab_size;
     HIPCHK(hipMemsetAsync(c->bp, 0, 65536 * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->ctl, 0, sizeof(DevCtl), c->stream));
+    {
+        DevCtl init = {};
+        init.n_live = n;         // every corpus byte starts as one live token
+        c->h_ctl = init;
+        HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl, sizeof(DevCtl), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipMemsetAsync(c->best, 0, ((size_t)c->n_target + 2) * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->L, 0, ((size_t)vocab_size * 2 + 8) * 4, c->stream));
 
@@ -433,7 +438,7 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     c->cur = 0;
     c->scur = 0;
     launch_widen(c->stream, c->d_text, n, c->d_endmask, c->tok[0], c->n_slots);
-    launch_summarize(c->stream, c->tok[0], c->sums[0], c->n_tiles, c->ctl, 1);
+    launch_summarize(c->stream, c->tok[0], c->sums[0], c->n_tiles, c->n_cus);
     launch_argmax(c->stream, c->tab, c->ctl, c->best);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     rc = sync_ctl(c);
@@ -474,7 +479,7 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
             const uint32_t X = 256 + c->k;
             if (c->opt_time_kernels) HIPCHK(hipEventRecord(c->kev[2 * i], c->stream));
             launch_merge(c->stream, c->tok[c->cur], c->sums[c->scur], c->sums[1 - c->scur], c->n_tiles,
-                         c->best + c->k, X, endbit, c->L, c->R, c->ctl, nullptr, nullptr);
+                         c->best + c->k, X, endbit, c->L, c->R, c->ctl, nullptr, nullptr, c->n_cus);
             if (c->opt_time_kernels) HIPCHK(hipEventRecord(c->kev[2 * i + 1], c->stream));
             c->scur = 1 - c->scur;
             launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->L, c->R, nullptr);

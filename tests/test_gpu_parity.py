@@ -168,8 +168,10 @@ def test_step_parity_chunked(tr, seed):
 
 
 def test_step_parity_runs_across_tiles(tr):
-    # runs of one byte far longer than a 2048-slot tile, odd and even lengths
-    parts = [b"a" * 5001, b"b", b"a" * 4096, b"cc", b"a" * 2047, b"d", b"a" * 2049, b"ab" * 3000]
+    # runs of one byte far longer than a 512-slot tile, odd and even lengths,
+    # ending exactly on / just before / just after tile and lane boundaries
+    parts = [b"a" * 5001, b"b", b"a" * 4096, b"cc", b"a" * 2047, b"d", b"a" * 2049, b"ab" * 3000,
+             b"a" * 511, b"e", b"a" * 513, b"f", b"a" * 7, b"g", b"a" * 8, b"h", b"a" * 9, b"ba" * 700]
     _step_parity(tr, b"".join(parts), None, 256 + 24, batch=1, compact_den=3)
 
 
