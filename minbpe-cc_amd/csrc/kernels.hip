@@ -18,6 +18,8 @@
 // prefetch their next tile while working on the current one.
 #include "mbpe_dev.h"
 
+#include <cstdlib>
+
 namespace mbpe {
 
 namespace {
@@ -478,9 +480,12 @@ __global__ void k_table_rehash(PairTable t, DevCtl *ctl) {
 //       m    += 1  per match                               => (a,b)-1
 //     which is the reference's sequential result: its transient (X,a)+1/-1
 //     on touching matches cancels (SURVEY.md 8-S rule 3).
-// Neighbour tokens across the tile edge come from the tile summaries of the
-// previous pass (ping-pong sin -> sout), never from the neighbour's slots, so
-// rewriting in place cannot race with a neighbour's reads.
+// Neighbour tokens across the tile edge come from the tile summaries (sin),
+// never from the neighbour's slots, so rewriting in place cannot race with a
+// neighbour's reads.  The summaries stay untouched during the pass: a changed
+// tile writes its new summary to a side array (sout) and sets its bit in a
+// bitmap; k_apply copies the marked entries over afterwards.  An unchanged
+// tile (nearly all of them) therefore costs no store at all.
 //
 // Most tiles hold no match: they are recognised from the 8 slots per lane
 // with a backward "next live token" chain and one ballot, and only cost the
@@ -488,27 +493,176 @@ __global__ void k_table_rehash(PairTable t, DevCtl *ctl) {
 
 struct TileIn {
     uint4 q;    // this lane's 8 slots
-    uint4 sm;   // lanes 0,1,2: summaries of tile-1, tile, tile+1
+    uint4 sm;   // lanes 0,1,2: summaries of tile-1, tile, tile+1 (one 16-byte load, 3 lanes active)
 };
 
-__device__ __forceinline__ TileIn tile_issue(const uint16_t *tok, const TileSum *sin, uint32_t n_tiles,
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Both loads are unconditional: a branch around a load makes hipcc wait
+// vmcnt(0) at the next use, which would drain the tiles prefetched behind
+// this one.  The three summaries come through a bounds-checked buffer load:
+// lanes 0..2 read tile-1 .. tile+1, every other lane (and a neighbour that
+// does not exist) points past the buffer and gets zeros without any traffic.
+__device__ __forceinline__ TileIn tile_issue(const uint16_t *tok, __amdgpu_buffer_rsrc_t sums_rsrc,
                                              uint32_t tile) {
     TileIn t;
     const uint32_t lane = lane_id();
     t.q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kWave + lane];
-    t.sm = make_uint4(0, 0, 0, 0);
-    const int64_t j = (int64_t)tile - 1 + lane;
-    if (lane < 3 && j >= 0 && j < (int64_t)n_tiles) t.sm = reinterpret_cast<const uint4 *>(sin)[j];
+    const uint32_t j = tile + lane - 1u;                       // tile 0, lane 0 wraps to 0xFFFFFFFF
+    const uint32_t off = (lane < 3 && j < 0x0FFFFFFFu) ? j * 16u : 0xFFFFFFF0u;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sums_rsrc, off, 0, 0);
+    t.sm = make_uint4(v.x, v.y, v.z, v.w);
     return t;
 }
 
+// The rare part of the merge pass: this tile may hold a match.  Exact
+// neighbours two deep on both sides, decisions, count deltas, in-place
+// rewrite and the tile's new summary.  Returns true when the summary was
+// written (the tile changed).
+template <bool CHUNKED>
+__device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *sin, TileSum *sout, uint32_t *chg,
+                                                uint32_t n_tiles,
+                                             uint32_t tile, uint32_t s[8], const Halo h, uint32_t a, uint32_t b,
+                                             uint32_t X, uint32_t *L, uint32_t *R, const RankEdge *le,
+                                             uint32_t &wave_m, uint32_t &wave_adj) {
+    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    const uint32_t lane = lane_id();
+    const bool same = a == b;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+
+    uint32_t cnt = 0, f1 = kSent, f2 = kSent, l1 = kSent, l2 = kSent;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (s[j] != kHole) {
+            if (cnt == 0) f1 = s[j]; else if (cnt == 1) f2 = s[j];
+            l2 = l1; l1 = s[j];
+            ++cnt;
+        }
+    }
+    const unsigned long long m_live = __ballot(cnt > 0);
+    // tokens before this lane
+    uint32_t p1_in, p2_in;
+    {
+        const unsigned long long lo = m_live & lt_mask;
+        const uint32_t src1 = lo ? 63u - (uint32_t)__builtin_clzll(lo) : lane;
+        const uint32_t sl1 = __shfl(l1, src1, kWave), sl2 = __shfl(l2, src1, kWave);
+        const unsigned long long lo2 = lo & ~(1ull << src1);
+        const uint32_t src2 = lo2 ? 63u - (uint32_t)__builtin_clzll(lo2) : lane;
+        const uint32_t tl1 = __shfl(l1, src2, kWave);
+        p1_in = lo ? sl1 : h.p1;
+        p2_in = lo ? (sl2 != kSent ? sl2 : (lo2 ? tl1 : h.p1)) : h.p2;
+    }
+    // tokens after this lane
+    uint32_t n1_in, n2_in;
+    {
+        const unsigned long long hi = m_live & gt_mask;
+        const uint32_t src1 = hi ? (uint32_t)__builtin_ctzll(hi) : lane;
+        const uint32_t sf1 = __shfl(f1, src1, kWave), sf2 = __shfl(f2, src1, kWave);
+        const unsigned long long hi2 = hi & ~(1ull << src1);
+        const uint32_t src2 = hi2 ? (uint32_t)__builtin_ctzll(hi2) : lane;
+        const uint32_t tf1 = __shfl(f1, src2, kWave);
+        n1_in = hi ? sf1 : h.n1;
+        n2_in = hi ? (sf2 != kSent ? sf2 : (hi2 ? tf1 : h.n1)) : h.n2;
+    }
+    uint32_t n1v[8], n2v[8];
+    {
+        uint32_t x1 = n1_in, x2 = n2_in;
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            n1v[j] = x1;
+            n2v[j] = x2;
+            if (s[j] != kHole) { x2 = x1; x1 = s[j]; }
+        }
+    }
+    // a == b: tokens equal to raw `a` immediately before this lane's first slot
+    uint32_t run = 0;
+    if (same) {
+        bool all_a = true;
+        uint32_t trail = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (s[j] != kHole) {
+                if (s[j] == a) ++trail; else { trail = 0; all_a = false; }
+            }
+        }
+        // inclusive scan of (all_a, trail): R after L -> R.all ? (L.all, L.trail + R.trail) : R
+        uint32_t sa = all_a ? 1u : 0u, st = trail;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t oa = __shfl_up(sa, d, kWave), ot = __shfl_up(st, d, kWave);
+            if (lane >= (uint32_t)d && sa) { st += ot; sa = oa; }
+        }
+        uint32_t ea = __shfl_up(sa, 1, kWave), et = __shfl_up(st, 1, kWave);
+        if (lane == 0) { ea = 1; et = 0; }
+        // lanes with ea set: the run reaches back to the start of the tile
+        unsigned long long rb = 0;
+        if (__ballot(ea && cnt > 0) != 0ull && h.p1 == a) rb = run_before_slow(sin, tile, a, le);
+        const uint32_t rb_small = (uint32_t)(rb & 1ull) | (rb >= 2 ? 2u : 0u);
+        run = ea ? et + rb_small : et;   // parity and ">= 2" are all that is used below
+    }
+
+    uint32_t my_m = 0, my_adj = 0;
+    bool changed = false;
+    uint32_t p1 = p1_in, p2 = p2_in;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t self = s[j];
+        if (self == kHole) continue;
+        const uint32_t n1 = n1v[j], n2 = n2v[j];
+        bool amatch, bmatch, prev_adjacent;
+        if (!same) {
+            amatch = (self == a) && ((n1 & idmask) == b);
+            bmatch = ((self & idmask) == b) && (p1 == a);
+            prev_adjacent = (p1 == b) && (p2 == a);
+        } else {
+            const bool is_a = (self & idmask) == a;
+            const bool odd = run & 1u;
+            amatch = (self == a) && !odd && ((n1 & idmask) == a);
+            bmatch = is_a && odd;
+            prev_adjacent = !odd && run >= 2;
+            run = (self == a) ? run + 1 : 0;
+        }
+        uint32_t nv = self;
+        if (amatch) {
+            nv = X | (n1 & endbit);
+            ++my_m;
+            if (p1 != kHole && !(p1 & endbit)) {
+                if (prev_adjacent) ++my_adj;
+                else atomicAdd(&L[p1], 1u);
+            }
+        } else if (bmatch) {
+            nv = kHole;
+            if (!(self & endbit) && n1 != kHole) {
+                const bool next_adjacent = (n1 == a) && ((n2 & idmask) == b);
+                if (!next_adjacent) atomicAdd(&R[n1 & idmask], 1u);
+            }
+        }
+        p2 = p1; p1 = self;       // neighbours are the OLD tokens
+        if (nv != self) { changed = true; s[j] = nv; }
+    }
+    if (changed) reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
+    wave_m += my_m;
+    wave_adj += my_adj;
+    if (__ballot(changed) == 0ull) return false;
+    const uint4 ns = wave_summary(s);
+    if (lane == 0) {
+        reinterpret_cast<uint4 *>(sout)[tile] = ns;
+        atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
+    }
+    return true;
+}
+
+template <bool CHUNKED, int DIAG>
 __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ tok,
                                                          const TileSum *__restrict__ sin,
                                                          TileSum *__restrict__ sout, uint32_t n_tiles,
+                                                         uint32_t *__restrict__ chg,
                                                          const unsigned long long *__restrict__ best_ptr,
-                                                         uint32_t X, uint32_t endbit, uint32_t *L,
-                                                         uint32_t *R, DevCtl *ctl, const RankEdge *le,
-                                                         const RankEdge *re) {
+                                                         uint32_t X, uint32_t *L, uint32_t *R, DevCtl *ctl,
+                                                         const RankEdge *le, const RankEdge *re) {
+    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
@@ -516,197 +670,68 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
     if (tile >= n_tiles) return;
 
     const unsigned long long best = *best_ptr;
-    if ((best >> 32) == 0) {
-        // count 0 (or no pair at all): nothing matches; keep the summaries valid
-        for (; tile < n_tiles; tile += n_waves)
-            if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = reinterpret_cast<const uint4 *>(sin)[tile];
-        return;
-    }
+    if ((best >> 32) == 0) return;   // count 0 (or no pair at all): nothing can match
     const uint32_t key = ~(uint32_t)best;
-    const uint32_t a = key >> 16, b = key & 0xFFFFu;
-    const bool same = a == b;
-    const uint32_t idmask = endbit ? 0x7FFFu : 0xFFFFu;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    const uint32_t a = rfl(key >> 16), b = rfl(key & 0xFFFFu);
 
     uint32_t wave_m = 0, wave_adj = 0;   // lane-local partial sums, reduced once at the end
 
-    TileIn cur = tile_issue(tok, sin, n_tiles, tile);
+    // three tiles in flight per wave while the current one is examined
+    // (past the end the last tile is re-read: loads stay unconditional)
+    const uint32_t last_tile = n_tiles - 1;
+    auto clamp_tile = [&](uint64_t t) { return (uint32_t)(t < n_tiles ? t : last_tile); };
+    const __amdgpu_buffer_rsrc_t sums_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
+    TileIn t0 = tile_issue(tok, sums_rsrc, tile);
+    TileIn t1 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + n_waves));
+    TileIn t2 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 2ull * n_waves));
+    bool v1 = (uint64_t)tile + n_waves < n_tiles, v2 = (uint64_t)tile + 2ull * n_waves < n_tiles;
     for (;;) {
-        const uint32_t next_tile = tile + n_waves;
-        const bool has_next = next_tile < n_tiles;
-        TileIn nxt;
-        if (has_next) nxt = tile_issue(tok, sin, n_tiles, next_tile);
+        const bool v3 = (uint64_t)tile + 3ull * n_waves < n_tiles;
+        TileIn t3 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 3ull * n_waves));
 
         // ---- this tile -------------------------------------------------------
-        const uint32_t me_nlive = rlane(cur.sm.z, 1) & 0xFFFFu;
-        bool copy_summary = true;
-        if (me_nlive != 0) {
+        const uint32_t me_nlive = rlane(t0.sm.z, 1) & 0xFFFFu;
+        if (DIAG == 1) {   // timing-only build: loads only
+            asm volatile("" :: "v"(t0.q.x), "v"(t0.q.y), "v"(t0.q.z), "v"(t0.q.w), "v"(t0.sm.x), "v"(t0.sm.y));
+        } else if (me_nlive != 0) {
             uint32_t s[8];
-            unpack8(cur.q, s);
+            unpack8(t0.q, s);
             // neighbours' edge tokens
             Halo h;
-            {
-                const uint32_t pw1 = rlane(cur.sm.y, 0), pw2 = rlane(cur.sm.z, 0);
-                const uint32_t nw0 = rlane(cur.sm.x, 2), nw2 = rlane(cur.sm.z, 2);
-                const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
-                if (fast) {
-                    h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
-                    h.n1 = nw0 & 0xFFFFu; h.n2 = nw0 >> 16;
-                } else {
-                    h = halo_slow(sin, n_tiles, tile, le, re);
-                }
+            const uint32_t pw1 = rlane(t0.sm.y, 0), pw2 = rlane(t0.sm.z, 0);
+            const uint32_t nw0 = rlane(t0.sm.x, 2), nw2 = rlane(t0.sm.z, 2);
+            const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
+            if (fast) {
+                h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
+                h.n1 = nw0 & 0xFFFFu; h.n2 = nw0 >> 16;
+            } else {
+                h = halo_slow(sin, n_tiles, tile, le, re);
             }
-            // next live token of every slot (backward chain inside the lane, then
-            // the first live token of the following lanes / the next tile)
-            uint32_t n1v[8];
-            uint32_t nx = kSent;
+            // Candidate test: some slot holds `a` and the next live token has id b.
+            // The chain starts from the next lane's first slot; when that slot is a
+            // hole the unknown token is treated as a wildcard (b), which can only
+            // send the tile to the exact path below without need.
+            uint32_t c = __shfl_down(s[0], 1, kWave);
+            if (c == kHole) c = b;
+            if (lane == kWave - 1) c = h.n1;
+            uint32_t acc = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                n1v[j] = nx;
-                if (s[j] != kHole) nx = s[j];
+                const uint32_t u = (CHUNKED ? (c & idmask) : c) ^ b;
+                const uint32_t tu = (s[j] ^ a) + u;      // 0 <=> s[j] == a and id(next live) == b
+                acc = tu < acc ? tu : acc;
+                c = s[j] != kHole ? s[j] : c;
             }
-            const uint32_t lane_first = nx;            // first live token of this lane
-            const unsigned long long m_live = __ballot(lane_first != kSent);
-            uint32_t src_hi;
-            {
-                const unsigned long long hi = m_live & gt_mask;
-                src_hi = hi ? (uint32_t)__builtin_ctzll(hi) : lane;
-                const uint32_t nf = __shfl(lane_first, src_hi, kWave);
-                const uint32_t n1_in = hi ? nf : h.n1;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (n1v[j] == kSent) n1v[j] = n1_in;
-            }
-            bool cand = false;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cand |= (s[j] == a) && ((n1v[j] & idmask) == b);
-            const bool work = __ballot(cand) != 0ull || h.p1 == a;
-
-            if (work) {
-                // ---- full path: neighbours two deep, decisions, deltas, rewrite ----
-                uint32_t cnt = 0, f2 = kSent, l1 = kSent, l2 = kSent;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (s[j] != kHole) {
-                        if (cnt == 1) f2 = s[j];
-                        l2 = l1; l1 = s[j];
-                        ++cnt;
-                    }
-                }
-                // tokens before this lane
-                uint32_t p1_in, p2_in;
-                {
-                    const unsigned long long lo = m_live & lt_mask;
-                    const uint32_t src1 = lo ? 63u - (uint32_t)__builtin_clzll(lo) : lane;
-                    const uint32_t sl1 = __shfl(l1, src1, kWave), sl2 = __shfl(l2, src1, kWave);
-                    const unsigned long long lo2 = lo & ~(1ull << src1);
-                    const uint32_t src2 = lo2 ? 63u - (uint32_t)__builtin_clzll(lo2) : lane;
-                    const uint32_t tl1 = __shfl(l1, src2, kWave);
-                    p1_in = lo ? sl1 : h.p1;
-                    p2_in = lo ? (sl2 != kSent ? sl2 : (lo2 ? tl1 : h.p1)) : h.p2;
-                }
-                // second token after this lane
-                uint32_t n1_in, n2_in;
-                {
-                    const unsigned long long hi = m_live & gt_mask;
-                    const uint32_t sf1 = __shfl(lane_first, src_hi, kWave), sf2 = __shfl(f2, src_hi, kWave);
-                    const unsigned long long hi2 = hi & ~(1ull << src_hi);
-                    const uint32_t src2 = hi2 ? (uint32_t)__builtin_ctzll(hi2) : lane;
-                    const uint32_t tf1 = __shfl(lane_first, src2, kWave);
-                    n1_in = hi ? sf1 : h.n1;
-                    n2_in = hi ? (sf2 != kSent ? sf2 : (hi2 ? tf1 : h.n1)) : h.n2;
-                }
-                uint32_t n2v[8];
-                {
-                    uint32_t x1 = n1_in, x2 = n2_in;
-#pragma unroll
-                    for (int j = 7; j >= 0; --j) {
-                        n2v[j] = x2;
-                        if (s[j] != kHole) { x2 = x1; x1 = s[j]; }
-                    }
-                }
-                // a == b: tokens equal to raw `a` immediately before this lane's first slot
-                uint32_t run = 0;
-                if (same) {
-                    bool all_a = true;
-                    uint32_t trail = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (s[j] != kHole) {
-                            if (s[j] == a) ++trail; else { trail = 0; all_a = false; }
-                        }
-                    }
-                    // inclusive scan of (all_a, trail): R after L -> R.all ? (L.all, L.trail + R.trail) : R
-                    uint32_t sa = all_a ? 1u : 0u, st = trail;
-#pragma unroll
-                    for (int d = 1; d < kWave; d <<= 1) {
-                        const uint32_t oa = __shfl_up(sa, d, kWave), ot = __shfl_up(st, d, kWave);
-                        if (lane >= (uint32_t)d && sa) { st += ot; sa = oa; }
-                    }
-                    uint32_t ea = __shfl_up(sa, 1, kWave), et = __shfl_up(st, 1, kWave);
-                    if (lane == 0) { ea = 1; et = 0; }
-                    // the run reaches the tile start for the lanes with ea set
-                    unsigned long long rb = 0;
-                    if (__ballot(ea && cnt > 0) != 0ull && h.p1 == a) rb = run_before_slow(sin, tile, a, le);
-                    const uint32_t rb_small = (uint32_t)(rb & 1ull) | (rb >= 2 ? 2u : 0u);
-                    run = ea ? et + rb_small : et;   // parity and ">= 2" are all that is used below
-                }
-
-                uint32_t my_m = 0, my_adj = 0;
-                bool changed = false;
-                uint32_t p1 = p1_in, p2 = p2_in;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t self = s[j];
-                    if (self == kHole) continue;
-                    const uint32_t n1 = n1v[j], n2 = n2v[j];
-                    bool amatch, bmatch, prev_adjacent;
-                    if (!same) {
-                        amatch = (self == a) && ((n1 & idmask) == b);
-                        bmatch = ((self & idmask) == b) && (p1 == a);
-                        prev_adjacent = (p1 == b) && (p2 == a);
-                    } else {
-                        const bool is_a = (self & idmask) == a;
-                        const bool odd = run & 1u;
-                        amatch = (self == a) && !odd && ((n1 & idmask) == a);
-                        bmatch = is_a && odd;
-                        prev_adjacent = !odd && run >= 2;
-                        run = (self == a) ? run + 1 : 0;
-                    }
-                    uint32_t nv = self;
-                    if (amatch) {
-                        nv = X | (n1 & endbit);
-                        ++my_m;
-                        if (p1 != kHole && !(p1 & endbit)) {
-                            if (prev_adjacent) ++my_adj;
-                            else atomicAdd(&L[p1], 1u);
-                        }
-                    } else if (bmatch) {
-                        nv = kHole;
-                        if (!(self & endbit) && n1 != kHole) {
-                            const bool next_adjacent = (n1 == a) && ((n2 & idmask) == b);
-                            if (!next_adjacent) atomicAdd(&R[n1 & idmask], 1u);
-                        }
-                    }
-                    p2 = p1; p1 = self;       // neighbours are the OLD tokens
-                    if (nv != self) { changed = true; s[j] = nv; }
-                }
-                if (changed)
-                    reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
-                wave_m += my_m;
-                wave_adj += my_adj;
-                if (__ballot(changed) != 0ull) {
-                    const uint4 ns = wave_summary(s);
-                    if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
-                    copy_summary = false;
-                }
-            }
+            bool work = __ballot(acc == 0u) != 0ull || h.p1 == a;
+            if (DIAG == 2) { asm volatile("" :: "v"(acc)); work = false; }
+            if (work) merge_tile_full<CHUNKED>(tok, sin, sout, chg, n_tiles, tile, s, h, a, b, X, L, R, le, wave_m, wave_adj);
         }
-        if (copy_summary && lane == 1) reinterpret_cast<uint4 *>(sout)[tile] = cur.sm;
 
-        if (!has_next) break;
-        tile = next_tile;
-        cur = nxt;
+        if (!v1) break;
+        tile += n_waves;
+        t0 = t1; t1 = t2; t2 = t3;
+        v1 = v2; v2 = v3;
     }
     const uint32_t tm = wave_sum(wave_m), ta = wave_sum(wave_adj);
     if (lane == 0) {
@@ -721,12 +746,24 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
 // ctl->m stays the LOCAL match count either way (it feeds n_live / holes).
 
 __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__restrict__ best_ptr,
-                        uint32_t X, uint32_t *L, uint32_t *R, const uint32_t *gm_gadj) {
+                        uint32_t X, uint32_t *L, uint32_t *R, const uint32_t *gm_gadj, TileSum *sums,
+                        const TileSum *side, uint32_t *chg, uint32_t n_chg_words) {
     const unsigned long long best = *best_ptr;
     if ((best >> 32) == 0) return;   // count 0: the merge changed nothing (also covers "no pair")
     const uint32_t key = ~(uint32_t)best;
     const uint32_t a = key >> 16, b = key & 0xFFFFu;
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    // summaries of the tiles the merge pass changed: side array -> live array
+    for (uint32_t w = x; w < n_chg_words; w += gridDim.x * blockDim.x) {
+        uint32_t bits = chg[w];
+        if (!bits) continue;
+        chg[w] = 0;
+        while (bits) {
+            const uint32_t tile = w * 32u + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            reinterpret_cast<uint4 *>(sums)[tile] = reinterpret_cast<const uint4 *>(side)[tile];
+        }
+    }
     if (x < X) {
         const uint32_t l = L[x];
         if (l) {
@@ -914,16 +951,40 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 }
 
 void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sin, TileSum *sout, uint32_t n_tiles,
-                  const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *L, uint32_t *R,
+                  uint32_t *chg, const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *L, uint32_t *R,
                   DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(k_merge, dim3(tile_grid(n_tiles, n_cus)), dim3(kMergeThreads), 0, s, tok, sin, sout, n_tiles,
-                       best, new_id, endbit, L, R, ctl, left_edge, right_edge);
+    const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
+#ifdef MBPE_DIAG
+    static const int diag = getenv("MBPE_MERGE_DIAG") ? atoi(getenv("MBPE_MERGE_DIAG")) : 0;
+    if (diag == 1 && !endbit) {
+        hipLaunchKernelGGL((k_merge<false, 1>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, L, R, ctl,
+                           left_edge, right_edge);
+        return;
+    }
+    if (diag == 2 && !endbit) {
+        hipLaunchKernelGGL((k_merge<false, 2>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, L, R, ctl,
+                           left_edge, right_edge);
+        return;
+    }
+#endif
+    if (endbit)
+        hipLaunchKernelGGL((k_merge<true, 0>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, L, R, ctl,
+                           left_edge, right_edge);
+    else
+        hipLaunchKernelGGL((k_merge<false, 0>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, L, R, ctl,
+                           left_edge, right_edge);
 }
 
 void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best, uint32_t new_id,
-                  uint32_t *L, uint32_t *R, const uint32_t *gm_gadj) {
-    hipLaunchKernelGGL(k_apply, dim3((new_id + 255) / 256), dim3(256), 0, s, t, ctl, best, new_id, L, R, gm_gadj);
+                  uint32_t *L, uint32_t *R, const uint32_t *gm_gadj, TileSum *sums, const TileSum *side,
+                  uint32_t *chg, uint32_t n_tiles) {
+    const uint32_t n_words = (n_tiles + 31u) / 32u;
+    uint32_t blocks = (new_id + 255) / 256;
+    const uint32_t want = (n_words + 255) / 256;
+    if (want > blocks) blocks = want < 2048 ? want : 2048;
+    hipLaunchKernelGGL(k_apply, dim3(blocks), dim3(256), 0, s, t, ctl, best, new_id, L, R, gm_gadj, sums, side, chg,
+                       n_words);
 }
 
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles, unsigned long long *offsets,

@@ -21,9 +21,10 @@ constexpr int kTile = 512;             // slots per tile = one wave x 8 slots (o
 constexpr int kMergeThreads = 256;     // 4 waves per workgroup, each wave walks its own tiles
 constexpr int kSlotsPerLane = 8;
 
-// What a tile exposes to its neighbours; written by the pass that last
-// changed the tile, read (never the neighbour's slots) by the next pass, so
-// in-place rewriting cannot race with halo reads.
+// What a tile exposes to its neighbours.  A merge pass reads these (never the
+// neighbour's slots) and leaves them untouched; the new summaries of changed
+// tiles are staged in a side array and folded in after the pass, so in-place
+// rewriting cannot race with halo reads.
 struct __attribute__((aligned(16))) TileSum {
     uint16_t head0, head1;   // first / second live token (kHole if absent)
     uint16_t tail1, tail0;   // second-last / last live token
@@ -109,15 +110,17 @@ void launch_table_rehash(hipStream_t s, PairTable t, DevCtl *ctl);
 // best[0] = max over entries of pack_best(count, key)   (best must be zeroed)
 void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best);
 
-// one merge pass over the stream, in place
-void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sin, TileSum *sout,
-                  uint32_t n_tiles, const unsigned long long *best, uint32_t new_id,
+// one merge pass over the stream, in place; new summaries of changed tiles go
+// to `side`, their bits are set in `chg` (launch_apply folds them into sums)
+void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sums, TileSum *side,
+                  uint32_t n_tiles, uint32_t *chg, const unsigned long long *best, uint32_t new_id,
                   uint32_t endbit, uint32_t *L, uint32_t *R, DevCtl *ctl,
                   const RankEdge *left_edge, const RankEdge *right_edge, int n_cus);
 
 // fold the merge's count deltas (L, R, m, adj) into the pair table
 void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best,
-                  uint32_t new_id, uint32_t *L, uint32_t *R, const uint32_t *gm_gadj);
+                  uint32_t new_id, uint32_t *L, uint32_t *R, const uint32_t *gm_gadj,
+                  TileSum *sums, const TileSum *side, uint32_t *chg, uint32_t n_tiles);
 
 // compaction: exclusive scan of n_live over tiles, then scatter
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles,

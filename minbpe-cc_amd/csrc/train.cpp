@@ -91,8 +91,9 @@ struct mbpe_ctx {
     uint64_t cap_slots = 0;      // allocated slots per buffer
     uint64_t n_slots = 0;        // physical slots in use (multiple of kTile)
     uint32_t n_tiles = 0;
-    TileSum *sums[2] = {nullptr, nullptr};
-    int scur = 0;
+    TileSum *sums = nullptr;     // live tile summaries
+    TileSum *side = nullptr;     // staging for the tiles a merge pass changed
+    uint32_t *chg = nullptr;     // bitmap of those tiles
     unsigned long long *offsets = nullptr;
 
     // pair table
@@ -139,7 +140,7 @@ int sync_ctl(mbpe_ctx *c) {
 
 void free_training(mbpe_ctx *c) {
     dfree(c->tok[0]); dfree(c->tok[1]);
-    dfree(c->sums[0]); dfree(c->sums[1]);
+    dfree(c->sums); dfree(c->side); dfree(c->chg);
     dfree(c->offsets);
     dfree(c->tab.hkey); dfree(c->tab.hidx); dfree(c->tab.ekey); dfree(c->tab.ecnt);
     dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->L);
@@ -203,16 +204,15 @@ int do_compact(mbpe_ctx *c) {
     // c->h_ctl must be current
     if (!c->n_tiles) return MBPE_OK;
     const int src = c->cur, dst = 1 - c->cur;
-    launch_tile_scan(c->stream, c->sums[c->scur], c->n_tiles, c->offsets, c->ctl);
-    launch_compact_scatter(c->stream, c->tok[src], c->sums[c->scur], c->offsets, c->n_tiles, c->tok[dst], c->n_cus);
+    launch_tile_scan(c->stream, c->sums, c->n_tiles, c->offsets, c->ctl);
+    launch_compact_scatter(c->stream, c->tok[src], c->sums, c->offsets, c->n_tiles, c->tok[dst], c->n_cus);
     const uint64_t live = c->h_ctl.n_live;
     const uint64_t padded = std::max<uint64_t>(round_up(live, kTile), kTile);
     launch_fill_u16(c->stream, c->tok[dst] + live, padded - live, (uint16_t)kHole);
     c->cur = dst;
     c->n_slots = padded;
     c->n_tiles = (uint32_t)(padded / kTile);
-    c->scur = 0;
-    launch_summarize(c->stream, c->tok[c->cur], c->sums[c->scur], c->n_tiles, c->n_cus);
+    launch_summarize(c->stream, c->tok[c->cur], c->sums, c->n_tiles, c->n_cus);
     DevCtl patch = c->h_ctl;
     patch.removed_total = 0;
     HIPCHK(hipMemcpyAsync(&c->ctl->removed_total, &patch.removed_total, sizeof(patch.removed_total),
@@ -407,10 +407,11 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     c->n_slots = std::max<uint64_t>(round_up(n, kTile), kTile);
     c->cap_slots = c->n_slots;
     c->n_tiles = (uint32_t)(c->n_slots / kTile);
-    for (int i = 0; i < 2; ++i) {
-        HIPCHK(hipMalloc(&c->tok[i], c->cap_slots * 2));
-        HIPCHK(hipMalloc(&c->sums[i], (size_t)c->n_tiles * sizeof(TileSum)));
-    }
+    for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->tok[i], c->cap_slots * 2));
+    HIPCHK(hipMalloc(&c->sums, (size_t)c->n_tiles * sizeof(TileSum)));
+    HIPCHK(hipMalloc(&c->side, (size_t)c->n_tiles * sizeof(TileSum)));
+    HIPCHK(hipMalloc(&c->chg, ((size_t)c->n_tiles / 32 + 2) * 4));
+    HIPCHK(hipMemsetAsync(c->chg, 0, ((size_t)c->n_tiles / 32 + 2) * 4, c->stream));
     HIPCHK(hipMalloc(&c->offsets, (size_t)c->n_tiles * 8));
     HIPCHK(hipMalloc(&c->bp, 65536 * 4));
     HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
@@ -436,9 +437,8 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     if (n >= 2) launch_pair_count_u8(c->stream, c->d_text, n, c->d_endmask, c->bp, c->n_cus);
     launch_table_init(c->stream, c->bp, c->tab, c->ctl);
     c->cur = 0;
-    c->scur = 0;
     launch_widen(c->stream, c->d_text, n, c->d_endmask, c->tok[0], c->n_slots);
-    launch_summarize(c->stream, c->tok[0], c->sums[0], c->n_tiles, c->n_cus);
+    launch_summarize(c->stream, c->tok[0], c->sums, c->n_tiles, c->n_cus);
     launch_argmax(c->stream, c->tab, c->ctl, c->best);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     rc = sync_ctl(c);
@@ -478,11 +478,11 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
         for (uint32_t i = 0; i < batch; ++i) {
             const uint32_t X = 256 + c->k;
             if (c->opt_time_kernels) HIPCHK(hipEventRecord(c->kev[2 * i], c->stream));
-            launch_merge(c->stream, c->tok[c->cur], c->sums[c->scur], c->sums[1 - c->scur], c->n_tiles,
-                         c->best + c->k, X, endbit, c->L, c->R, c->ctl, nullptr, nullptr, c->n_cus);
+            launch_merge(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best + c->k, X, endbit,
+                         c->L, c->R, c->ctl, nullptr, nullptr, c->n_cus);
             if (c->opt_time_kernels) HIPCHK(hipEventRecord(c->kev[2 * i + 1], c->stream));
-            c->scur = 1 - c->scur;
-            launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->L, c->R, nullptr);
+            launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->L, c->R, nullptr, c->sums, c->side, c->chg,
+                         c->n_tiles);
             launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1);
             c->k++;
         }

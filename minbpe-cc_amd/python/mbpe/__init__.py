@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-LIB_PATH = os.path.join(_PKG_DIR, "libmbpe.so")
+LIB_PATH = os.environ.get("MBPE_LIB") or os.path.join(_PKG_DIR, "libmbpe.so")
 
 OK = 0
 ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_VOCAB, ERR_STATE = -1, -2, -3, -4, -5
