@@ -174,35 +174,30 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__r
     for (uint32_t w = threadIdx.x; w < (uint32_t)kPcWords + 4; w += kPcThreads) hist[w] = 0;
     __syncthreads();
 
-    const uint64_t n_vec = (n + 15) / 16;
-    uint64_t per = (n_vec + gridDim.x - 1) / gridDim.x;
+    // The main loop handles the FULL 16-byte vectors; the ragged tail (< 16
+    // bytes, plus the pair that straddles into it) is left to one thread.
+    const uint64_t n_full = n / 16;
+    uint64_t per = (n_full + gridDim.x - 1) / gridDim.x;
     per = (per + kPcThreads - 1) / kPcThreads * kPcThreads;
     const uint64_t v_begin = per * blockIdx.x;
     uint64_t v_end = v_begin + per;
-    if (v_end > n_vec) v_end = n_vec;
+    if (v_end > n_full) v_end = n_full;
     const uint32_t lane = lane_id();
-    const uint64_t n_full = n / 16;            // vectors with all 16 bytes inside the text
+    const uint64_t last_vec = n_full ? n_full - 1 : 0;
 
-    // software pipeline: q/e/xb hold the vector of the NEXT iteration
+    // software pipeline: q/e/xb hold the vector of the NEXT iteration.  All
+    // loads are unconditional (clamped addresses): a branch around a load or
+    // an LDS atomic makes hipcc serialise them with full waits.
     uint4 q = make_uint4(0, 0, 0, 0);
     uint32_t e = 0, xb = 0;
     auto issue = [&](uint64_t base) {
-        const uint64_t vec = base + threadIdx.x;
-        q = make_uint4(0, 0, 0, 0);
-        e = 0;
-        xb = 0;
-        if (vec < v_end) {
-            const uint64_t byte0 = vec * 16;
-            if (vec < n_full) {
-                q = *reinterpret_cast<const uint4 *>(text + byte0);
-            } else {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint64_t i = byte0; i < n; ++i) w[(i - byte0) >> 2] |= (uint32_t)text[i] << (8 * ((i - byte0) & 3));
-                q = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            if (MASKED) e = reinterpret_cast<const uint16_t *>(endmask)[vec];
-            if (lane == kWave - 1 && byte0 + 16 < n) xb = text[byte0 + 16];
-        }
+        uint64_t vec = base + threadIdx.x;
+        vec = vec < last_vec ? vec : last_vec;
+        const uint64_t byte0 = vec * 16;
+        q = *reinterpret_cast<const uint4 *>(text + byte0);
+        if (MASKED) e = reinterpret_cast<const uint16_t *>(endmask)[vec];
+        const uint64_t nx = byte0 + 16 < n ? byte0 + 16 : n - 1;
+        xb = text[lane == kWave - 1 ? nx : byte0];     // only lane 63 uses it
     };
     if (v_begin < v_end) issue(v_begin);
 
@@ -210,36 +205,32 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__r
     for (uint64_t base = v_begin; base < v_end; base += kPcThreads) {
         const uint4 cq = q;
         const uint32_t ce = e, cxb = xb;
-        if (base + kPcThreads < v_end) issue(base + kPcThreads);
+        issue(base + kPcThreads < v_end ? base + kPcThreads : base);
 
         const uint64_t vec = base + threadIdx.x;
-        const uint64_t byte0 = vec * 16;
         // first byte of the next lane's vector = second byte of my last pair
         uint32_t nb = __shfl_down(cq.x, 1, kWave) & 0xFFu;
         if (lane == kWave - 1) nb = cxb;
-        // pairs that start in this vector: byte0 .. min(byte0+15, n-2)
-        uint32_t n_pairs = 0;
-        if (vec < v_end && byte0 + 1 < n) {
-            const uint64_t rem = n - 1 - byte0;
-            n_pairs = rem < 16 ? (uint32_t)rem : 16u;
-        }
-        uint32_t valid = n_pairs >= 16 ? 0xFFFFu : ((1u << n_pairs) - 1u);
+        // pairs that start in this vector: 16, or 15 for the last full vector (its
+        // straddling pair belongs to the tail thread below)
+        uint32_t valid = vec < v_end ? (vec + 1 < n_full ? 0xFFFFu : 0x7FFFu) : 0u;
         if (MASKED) valid &= ~ce;
         const uint32_t w[5] = {cq.x, cq.y, cq.z, cq.w, nb};
         uint32_t hot = 0;
+        uint32_t olds[16], masks[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int wi = i >> 2, sh = 8 * (i & 3);
             uint32_t bin;
             if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
             else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
-            const uint32_t half = bin >> 15;
-            const uint32_t inc = half ? 0x10000u : 1u;
-            if ((valid >> i) & 1u) {
-                const uint32_t old = atomicAdd(&hist[bin & 0x7FFFu], inc);
-                hot |= old & (inc * kPcHotBits);
-            }
+            uint32_t inc = (bin >> 15) ? 0x10000u : 1u;
+            inc = ((valid >> i) & 1u) ? inc : 0u;          // an invalid pair adds 0: no branch
+            masks[i] = inc * kPcHotBits;
+            olds[i] = atomicAdd(&hist[bin & 0x7FFFu], inc);
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hot |= olds[i] & masks[i];
         if (hot) *flag = 1;
         if (++epoch_iter == kPcEpochIters) {
             epoch_iter = 0;
@@ -255,6 +246,16 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__r
     }
     __syncthreads();
     pc_drain(hist, bp, 0);
+    // ragged tail: pairs starting at byte >= 16*n_full - 1 ... n-2
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        uint64_t i = n_full * 16;
+        if (i > 0) --i;                      // the pair straddling into the tail
+        if (n_full * 16 == n) i = n;         // no tail at all
+        for (; i + 1 < n; ++i) {
+            if (MASKED && ((endmask[i >> 3] >> (i & 7)) & 1u)) continue;
+            atomicAdd(&bp[((uint32_t)text[i] << 8) | text[i + 1]], 1u);
+        }
+    }
 }
 
 // ---- widen: byte corpus -> 16-bit slot stream ------------------------------
@@ -912,7 +913,7 @@ void launch_fill_u16(hipStream_t s, uint16_t *p, uint64_t n, uint16_t v) {
 void launch_pair_count_u8(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask,
                           uint32_t *bp, int n_workgroups) {
     if (n < 2) return;
-    uint64_t n_vec = (n + 15) / 16;
+    uint64_t n_vec = n / 16;
     uint64_t max_wg = (n_vec + kPcThreads - 1) / kPcThreads;
     if ((uint64_t)n_workgroups > max_wg) n_workgroups = (int)max_wg;
     if (n_workgroups < 1) n_workgroups = 1;
