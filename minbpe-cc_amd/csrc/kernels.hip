@@ -130,38 +130,58 @@ __global__ void k_fill_u16(uint16_t *p, uint64_t n, uint16_t v) {
 // One workgroup per CU keeps a private histogram of all 65,536 byte pairs in
 // LDS as packed 16-bit counters (128 KiB of the CU's 160 KiB).  Each lane
 // reads 16 corpus bytes with one 16-byte load (the next iteration's load is
-// issued before the current one is consumed) and issues 16 LDS atomics.
+// issued before the current one is consumed) and issues 16 fire-and-forget
+// LDS atomics: nothing in the inner loop waits for the LDS.
 //
 // bin = first | second << 8 (the little-endian 16-bit value at the pair's
-// offset); counter word = bin & 0x7FFF, half = bin >> 15.
+// offset), then bin ^= bin >> 8 so that the LDS bank (low bits) mixes both
+// bytes -- text uses few distinct first bytes; counter word = bin & 0x7FFF,
+// half = bin >> 15.
 //
 // Exactness of the 16-bit counters: an epoch is three iterations of the
-// 1024-thread workgroup = 49,152 increments.  A lane that sees a counter at
-// or above 0x2000 in the value returned by its atomic raises a flag; at the
-// epoch boundary a raised flag makes the workgroup drain every counter
-// >= 0x2000 to the global table.  So every counter is <= 0x2000 when an
-// epoch starts and gains at most 0xC000 inside it: it never wraps.
+// 1024-thread workgroup = 49,152 increments.  At every epoch boundary the
+// workgroup sweeps the histogram (conflict-free 16-byte LDS reads) and moves
+// every counter >= 0x2000 to the global table.  So every counter is < 0x2000
+// when an epoch starts and gains at most 0xC000 inside it: it never wraps.
 constexpr int kPcThreads = 1024;
 constexpr int kPcWords = 32768;            // 2 counters per word
 constexpr uint32_t kPcHotBits = 0xE000u;   // counter >= 0x2000
 constexpr int kPcEpochIters = 3;
 
-__device__ __forceinline__ uint32_t pc_table_index(uint32_t bin) {
-    return ((bin & 0xFFu) << 8) | (bin >> 8);   // -> (first << 8) | second
+__device__ __forceinline__ uint32_t pc_table_index(uint32_t hbin) {
+    const uint32_t bin = hbin ^ (hbin >> 8);         // undo the bank hash
+    return ((bin & 0xFFu) << 8) | (bin >> 8);        // -> (first << 8) | second
 }
 
-__device__ __forceinline__ void pc_drain(uint32_t *hist, uint32_t *bp, uint32_t hot_bits) {
-    // lanes walk consecutive OUTPUT indices so the global atomics of a wave
-    // are contiguous (the LDS reads are bank-conflicted, but this is rare)
-    for (uint32_t o = threadIdx.x; o < 65536u; o += kPcThreads) {
-        const uint32_t bin = ((o & 0xFFu) << 8) | (o >> 8);
-        const uint32_t w = bin & 0x7FFFu, sh = (bin >> 15) * 16;
-        const uint32_t v = hist[w];
-        const uint32_t c = (v >> sh) & 0xFFFFu;
-        if (c && (hot_bits == 0 || (c & hot_bits))) {
-            atomicAdd(&bp[o], c);
-            atomicAnd(&hist[w], ~(0xFFFFu << sh));
+// epoch sweep: thread t owns the 16-byte groups t, t+1024, ... of the histogram
+__device__ __forceinline__ void pc_sweep(uint32_t *hist, uint32_t *bp) {
+#pragma unroll
+    for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k) {
+        const uint32_t g = k * kPcThreads + threadIdx.x;
+        uint4 v = reinterpret_cast<uint4 *>(hist)[g];
+        const uint32_t any = (v.x | v.y | v.z | v.w) & (kPcHotBits | (kPcHotBits << 16));
+        if (any) {
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t word = g * 4 + c;
+                const uint32_t lo = w[c] & 0xFFFFu, hi = w[c] >> 16;
+                if (lo & kPcHotBits) { atomicAdd(&bp[pc_table_index(word)], lo); w[c] &= 0xFFFF0000u; }
+                if (hi & kPcHotBits) { atomicAdd(&bp[pc_table_index(word | 0x8000u)], hi); w[c] &= 0x0000FFFFu; }
+            }
+            reinterpret_cast<uint4 *>(hist)[g] = make_uint4(w[0], w[1], w[2], w[3]);
         }
+    }
+}
+
+// final flush: lanes walk consecutive OUTPUT indices so the global atomics of
+// a wave are contiguous (the LDS reads are bank-conflicted, but this runs once)
+__device__ __forceinline__ void pc_flush(const uint32_t *hist, uint32_t *bp) {
+    for (uint32_t o = threadIdx.x; o < 65536u; o += kPcThreads) {
+        uint32_t bin = ((o & 0xFFu) << 8) | (o >> 8);
+        bin ^= bin >> 8;
+        const uint32_t c = (hist[bin & 0x7FFFu] >> ((bin >> 15) * 16)) & 0xFFFFu;
+        if (c) atomicAdd(&bp[o], c);
     }
 }
 
@@ -169,9 +189,8 @@ template <bool MASKED>
 __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__restrict__ text, uint64_t n,
                                                               const uint8_t *__restrict__ endmask,
                                                               uint32_t *__restrict__ bp) {
-    __shared__ uint32_t hist[kPcWords + 4];
-    uint32_t *flag = &hist[kPcWords];
-    for (uint32_t w = threadIdx.x; w < (uint32_t)kPcWords + 4; w += kPcThreads) hist[w] = 0;
+    __shared__ uint32_t hist[kPcWords];
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kPcWords; w += kPcThreads) hist[w] = 0;
     __syncthreads();
 
     // The main loop handles the FULL 16-byte vectors; the ragged tail (< 16
@@ -216,37 +235,39 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__r
         uint32_t valid = vec < v_end ? (vec + 1 < n_full ? 0xFFFFu : 0x7FFFu) : 0u;
         if (MASKED) valid &= ~ce;
         const uint32_t w[5] = {cq.x, cq.y, cq.z, cq.w, nb};
-        uint32_t hot = 0;
-        uint32_t olds[16], masks[16];
+        if (__ballot(valid != 0xFFFFu) == 0ull) {
+            // every pair of every lane counts: no per-pair predicate
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int wi = i >> 2, sh = 8 * (i & 3);
-            uint32_t bin;
-            if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
-            else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
-            uint32_t inc = (bin >> 15) ? 0x10000u : 1u;
-            inc = ((valid >> i) & 1u) ? inc : 0u;          // an invalid pair adds 0: no branch
-            masks[i] = inc * kPcHotBits;
-            olds[i] = atomicAdd(&hist[bin & 0x7FFFu], inc);
+            for (int i = 0; i < 16; ++i) {
+                const int wi = i >> 2, sh = 8 * (i & 3);
+                uint32_t bin;
+                if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
+                else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
+                bin ^= bin >> 8;
+                atomicAdd(&hist[bin & 0x7FFFu], 1u + (bin >> 15) * 0xFFFFu);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int wi = i >> 2, sh = 8 * (i & 3);
+                uint32_t bin;
+                if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
+                else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
+                bin ^= bin >> 8;
+                const uint32_t inc = ((valid >> i) & 1u) ? 1u + (bin >> 15) * 0xFFFFu : 0u;   // invalid: add 0
+                atomicAdd(&hist[bin & 0x7FFFu], inc);
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) hot |= olds[i] & masks[i];
-        if (hot) *flag = 1;
         if (++epoch_iter == kPcEpochIters) {
             epoch_iter = 0;
             __syncthreads();
-            const uint32_t f = *flag;      // uniform: read between two barriers
+            pc_sweep(hist, bp);
             __syncthreads();
-            if (f) {
-                pc_drain(hist, bp, kPcHotBits);
-                if (threadIdx.x == 0) *flag = 0;
-                __syncthreads();
-            }
         }
     }
     __syncthreads();
-    pc_drain(hist, bp, 0);
-    // ragged tail: pairs starting at byte >= 16*n_full - 1 ... n-2
+    pc_flush(hist, bp);
+    // ragged tail: pairs starting at byte 16*n_full - 1 .. n-2
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         uint64_t i = n_full * 16;
         if (i > 0) --i;                      // the pair straddling into the tail
