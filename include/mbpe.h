@@ -36,6 +36,8 @@ extern "C" {
 #define MBPE_MAX_VOCAB_CHUNKED 32766u
 
 typedef enum {
+    MBPE_NEED_EXCHANGE =  1,  /* external-transport mode only: reduce the exchange buffer, then
+                                 call mbpe_comm_exchange_done */
     MBPE_OK            =  0,
     MBPE_ERR_ARG       = -1,  /* bad argument (NULL, vocab_size < 256: Tokenizer.h:492) */
     MBPE_ERR_NO_DEVICE = -2,  /* no HIP device / extension unusable */
@@ -179,6 +181,18 @@ MBPE_API int mbpe_set_option(mbpe_ctx *ctx, const char *name, int64_t value);
 MBPE_API int mbpe_comm_unique_id(uint8_t id_out[MBPE_COMM_ID_BYTES]);
 MBPE_API int mbpe_comm_init(mbpe_ctx *ctx, const uint8_t id[MBPE_COMM_ID_BYTES],
                             int rank, int n_ranks);
+
+/* The same sharded algorithm with the collective left to the caller (any
+ * transport that can sum u32 buffers across ranks: MPI, gloo, a test harness).
+ * After mbpe_comm_init_external, mbpe_train_begin and mbpe_train_steps return
+ * MBPE_NEED_EXCHANGE each time the ranks have to exchange data: the caller
+ * sum-all-reduces the buffer named by mbpe_comm_exchange_buffer (device
+ * memory, u32 elements, identical length on every rank) in place and calls
+ * mbpe_comm_exchange_done, which continues the operation and returns
+ * MBPE_NEED_EXCHANGE again (next merge) or MBPE_OK (operation complete). */
+MBPE_API int mbpe_comm_init_external(mbpe_ctx *ctx, int rank, int n_ranks);
+MBPE_API int mbpe_comm_exchange_buffer(mbpe_ctx *ctx, void **dev_ptr_out, uint64_t *n_u32_out);
+MBPE_API int mbpe_comm_exchange_done(mbpe_ctx *ctx);
 
 /* ---- host-side pieces of the reference path ------------------------- */
 

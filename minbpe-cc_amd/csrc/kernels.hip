@@ -498,6 +498,8 @@ __global__ void k_table_rehash(PairTable t, DevCtl *ctl) {
 //   - count deltas (:239-280) are accumulated as
 //       L[x] += 1  for a match whose left neighbour is x   => (x,a)-1, (x,X)+1
 //       R[y] += 1  for a match whose right neighbour is y  => (b,y)-1, (X,y)+1
+//     (L[x] = LR[2x], R[y] = LR[2y+1]: one array, so that a multi-GPU run
+//      all-reduces a contiguous prefix)
 //       adj  += 1  for two matches that touch ("abab")     => (b,a)-1, (X,X)+1
 //       m    += 1  per match                               => (a,b)-1
 //     which is the reference's sequential result: its transient (X,a)+1/-1
@@ -545,8 +547,8 @@ template <bool CHUNKED>
 __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *sin, TileSum *sout, uint32_t *chg,
                                                 uint32_t n_tiles,
                                              uint32_t tile, uint32_t s[8], const Halo h, uint32_t a, uint32_t b,
-                                             uint32_t X, uint32_t *L, uint32_t *R, const RankEdge *le,
-                                             uint32_t &wave_m, uint32_t &wave_adj) {
+                                             uint32_t X, uint32_t *LR, const RankEdge *le,
+                                             uint32_t &wave_m, uint32_t &wave_adj, uint32_t &wave_rm) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     const uint32_t lane = lane_id();
@@ -625,7 +627,7 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
         run = ea ? et + rb_small : et;   // parity and ">= 2" are all that is used below
     }
 
-    uint32_t my_m = 0, my_adj = 0;
+    uint32_t my_m = 0, my_adj = 0, my_rm = 0;
     bool changed = false;
     uint32_t p1 = p1_in, p2 = p2_in;
 #pragma unroll
@@ -652,13 +654,14 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
             ++my_m;
             if (p1 != kHole && !(p1 & endbit)) {
                 if (prev_adjacent) ++my_adj;
-                else atomicAdd(&L[p1], 1u);
+                else atomicAdd(&LR[2u * p1], 1u);
             }
         } else if (bmatch) {
             nv = kHole;
+            ++my_rm;
             if (!(self & endbit) && n1 != kHole) {
                 const bool next_adjacent = (n1 == a) && ((n2 & idmask) == b);
-                if (!next_adjacent) atomicAdd(&R[n1 & idmask], 1u);
+                if (!next_adjacent) atomicAdd(&LR[2u * (n1 & idmask) + 1u], 1u);
             }
         }
         p2 = p1; p1 = self;       // neighbours are the OLD tokens
@@ -667,6 +670,7 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
     if (changed) reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
     wave_m += my_m;
     wave_adj += my_adj;
+    wave_rm += my_rm;
     if (__ballot(changed) == 0ull) return false;
     const uint4 ns = wave_summary(s);
     if (lane == 0) {
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
                                                          TileSum *__restrict__ sout, uint32_t n_tiles,
                                                          uint32_t *__restrict__ chg,
                                                          const unsigned long long *__restrict__ best_ptr,
-                                                         uint32_t X, uint32_t *L, uint32_t *R, DevCtl *ctl,
+                                                         uint32_t X, uint32_t *LR, DevCtl *ctl,
                                                          const RankEdge *le, const RankEdge *re) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     const uint32_t lane = lane_id();
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
     const uint32_t key = ~(uint32_t)best;
     const uint32_t a = rfl(key >> 16), b = rfl(key & 0xFFFFu);
 
-    uint32_t wave_m = 0, wave_adj = 0;   // lane-local partial sums, reduced once at the end
+    uint32_t wave_m = 0, wave_adj = 0, wave_rm = 0;   // lane-local partial sums, reduced once at the end
 
     // three tiles in flight per wave while the current one is examined
     // (past the end the last tile is re-read: loads stay unconditional)
@@ -747,7 +751,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
             }
             bool work = __ballot(acc == 0u) != 0ull || h.p1 == a;
             if (DIAG == 2) { asm volatile("" :: "v"(acc)); work = false; }
-            if (work) merge_tile_full<CHUNKED>(tok, sin, sout, chg, n_tiles, tile, s, h, a, b, X, L, R, le, wave_m, wave_adj);
+            if (work) merge_tile_full<CHUNKED>(tok, sin, sout, chg, n_tiles, tile, s, h, a, b, X, LR, le, wave_m, wave_adj,
+                                                   wave_rm);
         }
 
         if (!v1) break;
@@ -755,28 +760,23 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
         t0 = t1; t1 = t2; t2 = t3;
         v1 = v2; v2 = v3;
     }
-    const uint32_t tm = wave_sum(wave_m), ta = wave_sum(wave_adj);
+    const uint32_t tm = wave_sum(wave_m), ta = wave_sum(wave_adj), tr = wave_sum(wave_rm);
     if (lane == 0) {
         if (tm) atomicAdd(&ctl->m, tm);
         if (ta) atomicAdd(&ctl->adj, ta);
+        if (tr) atomicAdd(&ctl->rm, tr);
     }
 }
 
 // ---- apply: fold (L, R, m, adj) into the pair table -------------------------------
 // gm_gadj, when not NULL, holds the all-reduced {m, adj} of a multi-GPU run
-// (L and R are then already all-reduced in place); otherwise ctl->m / ctl->adj.
-// ctl->m stays the LOCAL match count either way (it feeds n_live / holes).
+// (LR is then already all-reduced in place); otherwise ctl->m / ctl->adj.
+// n_live / holes follow ctl->rm, the tokens removed from this rank's shard.
 
-__global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__restrict__ best_ptr,
-                        uint32_t X, uint32_t *L, uint32_t *R, const uint32_t *gm_gadj, TileSum *sums,
-                        const TileSum *side, uint32_t *chg, uint32_t n_chg_words) {
-    const unsigned long long best = *best_ptr;
-    if ((best >> 32) == 0) return;   // count 0: the merge changed nothing (also covers "no pair")
-    const uint32_t key = ~(uint32_t)best;
-    const uint32_t a = key >> 16, b = key & 0xFFFFu;
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void patch_sums(TileSum *sums, const TileSum *side, uint32_t *chg, uint32_t n_chg_words,
+                                           uint32_t first, uint32_t stride) {
     // summaries of the tiles the merge pass changed: side array -> live array
-    for (uint32_t w = x; w < n_chg_words; w += gridDim.x * blockDim.x) {
+    for (uint32_t w = first; w < n_chg_words; w += stride) {
         uint32_t bits = chg[w];
         if (!bits) continue;
         chg[w] = 0;
@@ -786,19 +786,34 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
             reinterpret_cast<uint4 *>(sums)[tile] = reinterpret_cast<const uint4 *>(side)[tile];
         }
     }
+}
+
+__global__ void k_patch_sums(const unsigned long long *__restrict__ best_ptr, TileSum *sums, const TileSum *side,
+                             uint32_t *chg, uint32_t n_chg_words) {
+    if ((*best_ptr >> 32) == 0) return;
+    patch_sums(sums, side, chg, n_chg_words, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+__global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__restrict__ best_ptr,
+                        uint32_t X, uint32_t *LR, const uint32_t *gm_gadj, TileSum *sums,
+                        const TileSum *side, uint32_t *chg, uint32_t n_chg_words) {
+    const unsigned long long best = *best_ptr;
+    if ((best >> 32) == 0) return;   // count 0: the merge changed nothing (also covers "no pair")
+    const uint32_t key = ~(uint32_t)best;
+    const uint32_t a = key >> 16, b = key & 0xFFFFu;
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    patch_sums(sums, side, chg, n_chg_words, x, gridDim.x * blockDim.x);
     if (x < X) {
-        const uint32_t l = L[x];
-        if (l) {
-            table_add(t, ctl, (x << 16) | a, -(int32_t)l, false);
-            table_add(t, ctl, (x << 16) | X, (int32_t)l, true);
-            L[x] = 0;
+        const uint2 lr = reinterpret_cast<uint2 *>(LR)[x];
+        if (lr.x) {
+            table_add(t, ctl, (x << 16) | a, -(int32_t)lr.x, false);
+            table_add(t, ctl, (x << 16) | X, (int32_t)lr.x, true);
         }
-        const uint32_t r = R[x];
-        if (r) {
-            table_add(t, ctl, (b << 16) | x, -(int32_t)r, false);
-            table_add(t, ctl, (X << 16) | x, (int32_t)r, true);
-            R[x] = 0;
+        if (lr.y) {
+            table_add(t, ctl, (b << 16) | x, -(int32_t)lr.y, false);
+            table_add(t, ctl, (X << 16) | x, (int32_t)lr.y, true);
         }
+        if (lr.x | lr.y) reinterpret_cast<uint2 *>(LR)[x] = make_uint2(0, 0);
     }
     if (x == 0) {
         const uint32_t m_local = ctl->m;
@@ -809,10 +824,14 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
             table_add(t, ctl, (b << 16) | a, -(int32_t)adj, false);
             table_add(t, ctl, (X << 16) | X, (int32_t)adj, true);
         }
-        ctl->removed_total += m_local;
-        ctl->n_live -= m_local;
+        // tokens removed from this shard = second tokens of matches it holds (with
+        // several ranks a match can straddle two shards, so this is not m)
+        const uint32_t rm = ctl->rm;
+        ctl->removed_total += rm;
+        ctl->n_live -= rm;
         ctl->m = 0;
         ctl->adj = 0;
+        ctl->rm = 0;
     }
 }
 
@@ -863,9 +882,13 @@ __global__ __launch_bounds__(kMergeThreads) void k_compact_scatter(const uint16_
     }
 }
 
-// ---- rank edge (multi-GPU) ---------------------------------------------------------------
+// ---- multi-GPU: rank edges ------------------------------------------------------------
+// Exchange header of one merge (u32 words): [0] m, [1] adj, [2 + 8r ..] the
+// RankEdge of rank r.  Every rank fills only its own slot (the others stay 0),
+// so the sum all-reduce of the buffer doubles as an all-gather of the edges.
 
-__global__ void k_rank_edge(const TileSum *__restrict__ sums, uint32_t n_tiles, RankEdge *out) {
+__global__ void k_rank_edge(const TileSum *__restrict__ sums, uint32_t n_tiles, RankEdge *out, const DevCtl *ctl,
+                            uint32_t *hdr) {
     if (blockIdx.x || threadIdx.x) return;
     RankEdge e;
     e.head0 = e.head1 = e.tail0 = e.tail1 = kHole;
@@ -884,19 +907,77 @@ __global__ void k_rank_edge(const TileSum *__restrict__ sums, uint32_t n_tiles, 
         if (need == 2) { e.tail0 = s.tail0; need = 1; if (s.n_live >= 2) { e.tail1 = s.tail1; need = 0; } }
         else { e.tail1 = s.tail0; need = 0; }
     }
-    unsigned long long run = 0, live = 0;
-    bool counting = true;
+    unsigned long long run = 0;
     for (int64_t j = (int64_t)n_tiles - 1; j >= 0; --j) {
         TileSum s = sums[j];
-        live += s.n_live;
-        if (!counting || !s.n_live) continue;
-        if (s.tail0 != e.tail0) { counting = false; continue; }
+        if (!s.n_live) continue;
+        if (s.tail0 != e.tail0) break;
         run += s.tail_run;
-        if (s.tail_run != s.n_live) counting = false;
+        if (s.tail_run != s.n_live) break;
     }
+    const unsigned long long live = ctl->n_live - ctl->rm;   // ctl->rm is folded in by k_apply later
     e.n_live_lo = (uint32_t)live; e.n_live_hi = (uint32_t)(live >> 32);
     e.tail_run_lo = (uint32_t)run; e.tail_run_hi = (uint32_t)(run >> 32);
+    // kHole (0xFFFF) must survive a SUM with zeros from the other ranks: it does.
     *out = e;
+    if (hdr) { hdr[0] = ctl->m; hdr[1] = ctl->adj; }
+}
+
+// What lies to the left / right of this rank's shard, looked through empty
+// ranks: left.tail0/tail1/tail_run and right.head0/head1 in RankEdge form.
+// Also clears the exchange header for the next merge.
+__global__ void k_compose_edges(uint32_t *hdr, int rank, int n_ranks, RankEdge *left, RankEdge *right) {
+    if (blockIdx.x || threadIdx.x) return;
+    const RankEdge *all = reinterpret_cast<const RankEdge *>(hdr + 2);
+    RankEdge l, r;
+    l.head0 = l.head1 = l.tail0 = l.tail1 = kHole;
+    l.n_live_lo = l.n_live_hi = l.tail_run_lo = l.tail_run_hi = 0;
+    r = l;
+    int need = 2;
+    for (int j = rank - 1; need && j >= 0; --j) {
+        const RankEdge e = all[j];
+        const uint32_t nl = e.tail0 == kHole ? 0 : (e.tail1 == kHole ? 1 : 2);
+        if (!nl) continue;
+        if (need == 2) { l.tail0 = e.tail0; need = 1; if (nl >= 2) { l.tail1 = e.tail1; need = 0; } }
+        else { l.tail1 = e.tail0; need = 0; }
+    }
+    unsigned long long run = 0;
+    for (int j = rank - 1; j >= 0; --j) {
+        const RankEdge e = all[j];
+        const unsigned long long live = ((unsigned long long)e.n_live_hi << 32) | e.n_live_lo;
+        if (!live) continue;
+        if (e.tail0 != l.tail0) break;
+        const unsigned long long tr = ((unsigned long long)e.tail_run_hi << 32) | e.tail_run_lo;
+        run += tr;
+        if (tr != live) break;
+    }
+    l.tail_run_lo = (uint32_t)run; l.tail_run_hi = (uint32_t)(run >> 32);
+    need = 2;
+    for (int j = rank + 1; need && j < n_ranks; ++j) {
+        const RankEdge e = all[j];
+        const uint32_t nl = e.head0 == kHole ? 0 : (e.head1 == kHole ? 1 : 2);
+        if (!nl) continue;
+        if (need == 2) { r.head0 = e.head0; need = 1; if (nl >= 2) { r.head1 = e.head1; need = 0; } }
+        else { r.head1 = e.head0; need = 0; }
+    }
+    *left = l;
+    *right = r;
+    for (int i = 0; i < 2 + 8 * n_ranks; ++i) hdr[i] = 0;
+}
+
+// Begin of a multi-GPU run: the byte pairs that straddle two ranks' shards
+// are added to the (already all-reduced) byte-pair table by every rank alike.
+__global__ void k_boundary_pairs(uint32_t *bp, const uint32_t *hdr, int n_ranks, uint32_t endbit) {
+    if (blockIdx.x || threadIdx.x) return;
+    const RankEdge *all = reinterpret_cast<const RankEdge *>(hdr + 2);
+    uint32_t prev_tail = kHole;
+    for (int j = 0; j < n_ranks; ++j) {
+        const RankEdge e = all[j];
+        if (e.head0 == kHole) continue;            // empty shard
+        if (prev_tail != kHole && !(prev_tail & endbit))
+            bp[((prev_tail & 0xFFu) << 8) | (e.head0 & 0xFFu)] += 1;
+        prev_tail = e.tail0;
+    }
 }
 
 inline int blocks_for(uint64_t n, int threads, int max_blocks) {
@@ -973,40 +1054,49 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 }
 
 void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sin, TileSum *sout, uint32_t n_tiles,
-                  uint32_t *chg, const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *L, uint32_t *R,
+                  uint32_t *chg, const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *LR,
                   DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus) {
     if (!n_tiles) return;
     const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_MERGE_DIAG") ? atoi(getenv("MBPE_MERGE_DIAG")) : 0;
     if (diag == 1 && !endbit) {
-        hipLaunchKernelGGL((k_merge<false, 1>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, L, R, ctl,
+        hipLaunchKernelGGL((k_merge<false, 1>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            left_edge, right_edge);
         return;
     }
     if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_merge<false, 2>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, L, R, ctl,
+        hipLaunchKernelGGL((k_merge<false, 2>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            left_edge, right_edge);
         return;
     }
 #endif
     if (endbit)
-        hipLaunchKernelGGL((k_merge<true, 0>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, L, R, ctl,
+        hipLaunchKernelGGL((k_merge<true, 0>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            left_edge, right_edge);
     else
-        hipLaunchKernelGGL((k_merge<false, 0>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, L, R, ctl,
+        hipLaunchKernelGGL((k_merge<false, 0>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            left_edge, right_edge);
 }
 
 void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best, uint32_t new_id,
-                  uint32_t *L, uint32_t *R, const uint32_t *gm_gadj, TileSum *sums, const TileSum *side,
+                  uint32_t *LR, const uint32_t *gm_gadj, TileSum *sums, const TileSum *side,
                   uint32_t *chg, uint32_t n_tiles) {
     const uint32_t n_words = (n_tiles + 31u) / 32u;
     uint32_t blocks = (new_id + 255) / 256;
     const uint32_t want = (n_words + 255) / 256;
     if (want > blocks) blocks = want < 2048 ? want : 2048;
-    hipLaunchKernelGGL(k_apply, dim3(blocks), dim3(256), 0, s, t, ctl, best, new_id, L, R, gm_gadj, sums, side, chg,
+    hipLaunchKernelGGL(k_apply, dim3(blocks), dim3(256), 0, s, t, ctl, best, new_id, LR, gm_gadj, sums, side, chg,
                        n_words);
+}
+
+void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *sums, const TileSum *side,
+                       uint32_t *chg, uint32_t n_tiles) {
+    const uint32_t n_words = (n_tiles + 31u) / 32u;
+    uint32_t blocks = (n_words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_patch_sums, dim3(blocks), dim3(256), 0, s, best, sums, side, chg, n_words);
 }
 
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles, unsigned long long *offsets,
@@ -1021,8 +1111,17 @@ void launch_compact_scatter(hipStream_t s, const uint16_t *src, const TileSum *s
                        offsets, n_tiles, dst);
 }
 
-void launch_rank_edge(hipStream_t s, const TileSum *sums, uint32_t n_tiles, RankEdge *out) {
-    hipLaunchKernelGGL(k_rank_edge, dim3(1), dim3(64), 0, s, sums, n_tiles, out);
+void launch_rank_edge(hipStream_t s, const TileSum *sums, uint32_t n_tiles, RankEdge *out, const DevCtl *ctl,
+                      uint32_t *hdr) {
+    hipLaunchKernelGGL(k_rank_edge, dim3(1), dim3(64), 0, s, sums, n_tiles, out, ctl, hdr);
+}
+
+void launch_compose_edges(hipStream_t s, uint32_t *hdr, int rank, int n_ranks, RankEdge *left, RankEdge *right) {
+    hipLaunchKernelGGL(k_compose_edges, dim3(1), dim3(64), 0, s, hdr, rank, n_ranks, left, right);
+}
+
+void launch_boundary_pairs(hipStream_t s, uint32_t *bp, const uint32_t *hdr, int n_ranks, uint32_t endbit) {
+    hipLaunchKernelGGL(k_boundary_pairs, dim3(1), dim3(64), 0, s, bp, hdr, n_ranks, endbit);
 }
 
 }  // namespace mbpe

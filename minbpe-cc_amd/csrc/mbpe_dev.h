@@ -68,7 +68,8 @@ struct DevCtl {
     unsigned long long removed_total;  // holes created since the last compaction
     unsigned long long n_live;         // live tokens in this rank's shard
     unsigned long long scan_total;     // output of the tile scan (compaction)
-    uint32_t pad[6];
+    uint32_t rm;             // tokens removed from THIS rank's shard by the current merge
+    uint32_t pad[5];
 };
 
 constexpr uint32_t kErrTableFull   = 1u;
@@ -114,13 +115,17 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 // to `side`, their bits are set in `chg` (launch_apply folds them into sums)
 void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sums, TileSum *side,
                   uint32_t n_tiles, uint32_t *chg, const unsigned long long *best, uint32_t new_id,
-                  uint32_t endbit, uint32_t *L, uint32_t *R, DevCtl *ctl,
+                  uint32_t endbit, uint32_t *LR, DevCtl *ctl,
                   const RankEdge *left_edge, const RankEdge *right_edge, int n_cus);
 
 // fold the merge's count deltas (L, R, m, adj) into the pair table
+// (L[x] = LR[2x], R[y] = LR[2y+1])
 void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best,
-                  uint32_t new_id, uint32_t *L, uint32_t *R, const uint32_t *gm_gadj,
+                  uint32_t new_id, uint32_t *LR, const uint32_t *gm_gadj,
                   TileSum *sums, const TileSum *side, uint32_t *chg, uint32_t n_tiles);
+// only the summary fold of launch_apply (multi-GPU: it must precede the rank edge)
+void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *sums, const TileSum *side,
+                       uint32_t *chg, uint32_t n_tiles);
 
 // compaction: exclusive scan of n_live over tiles, then scatter
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles,
@@ -128,8 +133,15 @@ void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles,
 void launch_compact_scatter(hipStream_t s, const uint16_t *src, const TileSum *sums,
                             const unsigned long long *offsets, uint32_t n_tiles, uint16_t *dst, int n_cus);
 
-// this rank's RankEdge from its tile summaries
-void launch_rank_edge(hipStream_t s, const TileSum *sums, uint32_t n_tiles, RankEdge *out);
+// multi-GPU exchange header (u32 words): [0] m, [1] adj, [2 + 8r ..] RankEdge of rank r
+inline uint32_t exchange_header_words(int n_ranks) { return (uint32_t)((2 + 8 * n_ranks + 3) / 4 * 4); }
+// this rank's RankEdge from its tile summaries (+ m, adj into the header when hdr != NULL)
+void launch_rank_edge(hipStream_t s, const TileSum *sums, uint32_t n_tiles, RankEdge *out, const DevCtl *ctl,
+                      uint32_t *hdr);
+// neighbours of this rank's shard from the gathered edges; clears the header
+void launch_compose_edges(hipStream_t s, uint32_t *hdr, int rank, int n_ranks, RankEdge *left, RankEdge *right);
+// begin: pairs straddling rank boundaries -> byte-pair table
+void launch_boundary_pairs(hipStream_t s, uint32_t *bp, const uint32_t *hdr, int n_ranks, uint32_t endbit);
 
 }  // namespace mbpe
 

@@ -13,6 +13,9 @@
 #include "mbpe_dev.h"
 #include "../host/mbpe_host.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -69,6 +72,43 @@ void dfree(T *&p) {
 
 }  // namespace
 
+// ---- RCCL, bound at run time: the library loads and runs on one GPU without it ----
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) { r.why = "librccl.so.1 not found"; return r; }
+#define MBPE_BIND(field, name) \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name)); \
+    if (!r.field) { r.why = std::string("missing RCCL symbol ") + name; return r; }
+    MBPE_BIND(GetUniqueId, "ncclGetUniqueId")
+    MBPE_BIND(CommInitRank, "ncclCommInitRank")
+    MBPE_BIND(CommDestroy, "ncclCommDestroy")
+    MBPE_BIND(AllReduce, "ncclAllReduce")
+    MBPE_BIND(GetErrorString, "ncclGetErrorString")
+#undef MBPE_BIND
+    r.ok = true;
+    return r;
+}
+}  // namespace
+
 struct mbpe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -99,10 +139,15 @@ struct mbpe_ctx {
     // pair table
     PairTable tab = {};
     uint32_t hcap = 0;
-    uint32_t *bp = nullptr;      // 65,536 byte-pair counts
+    uint32_t *bp = nullptr;      // unused (the byte-pair table is the front of xb0)
     DevCtl *ctl = nullptr;
     unsigned long long *best = nullptr;   // [n_target + 1]
-    uint32_t *L = nullptr, *R = nullptr;  // [vocab_size] each, contiguous (L then R then gm,gadj)
+    // exchange buffer of one merge: [header: m, adj, RankEdge x n_ranks][LR: L[x], R[x] interleaved]
+    uint32_t *xb = nullptr;
+    uint32_t hdr_words = 0;
+    uint32_t *LR = nullptr;               // xb + hdr_words
+    uint32_t *xb0 = nullptr;              // begin: [bp 65,536][header]
+    RankEdge *d_left = nullptr, *d_right = nullptr;   // composed neighbours (multi-GPU)
 
     // training
     uint32_t vocab_size = 0;
@@ -112,6 +157,13 @@ struct mbpe_ctx {
     bool begun = false;
     bool exhausted = false;
     DevCtl h_ctl = {};
+
+    // multi-GPU
+    int rank = 0, n_ranks = 1;
+    bool comm_external = false;           // the caller performs the all-reduce
+    void *nccl_comm = nullptr;
+    int pending = 0;                      // external mode: 0 none, 1 begin, 2 step
+    uint32_t pending_steps = 0, pending_done = 0;
 
     // options
     int64_t opt_compact_den = 8;
@@ -143,8 +195,10 @@ void free_training(mbpe_ctx *c) {
     dfree(c->sums); dfree(c->side); dfree(c->chg);
     dfree(c->offsets);
     dfree(c->tab.hkey); dfree(c->tab.hidx); dfree(c->tab.ekey); dfree(c->tab.ecnt);
-    dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->L);
-    c->R = nullptr;
+    dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->xb); dfree(c->xb0);
+    dfree(c->d_left); dfree(c->d_right);
+    c->LR = nullptr;
+    c->pending = 0;
     c->begun = false;
     c->k = c->n_valid = 0;
     c->exhausted = false;
@@ -257,6 +311,7 @@ void mbpe_destroy(mbpe_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_training(c);
     free_corpus(c);
+    if (c->nccl_comm && rccl().ok) rccl().CommDestroy(c->nccl_comm);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -386,16 +441,14 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
     return MBPE_OK;
 }
 
-int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
-    if (!c) return MBPE_ERR_ARG;
-    if (!c->loaded) { mbpe_host::set_last_error("mbpe_train_begin: no corpus loaded"); return MBPE_ERR_STATE; }
-    if (vocab_size < 256) { mbpe_host::set_last_error("vocab_size must be >= 256"); return MBPE_ERR_ARG; }
-    const uint32_t vmax = c->chunked ? MBPE_MAX_VOCAB_CHUNKED : MBPE_MAX_VOCAB_BASIC;
-    if (vocab_size > vmax) {
-        mbpe_host::set_last_error("vocab_size exceeds the 16-bit slot format (" + std::to_string(vmax) + ")");
-        return MBPE_ERR_VOCAB;
-    }
-    HIPCHK(hipSetDevice(c->device));
+// ---- training phases ---------------------------------------------------------
+// begin  = begin_local  -> [all-reduce xb0] -> begin_finish
+// step   = step_local   -> [all-reduce xb ] -> step_finish
+// With one rank the exchange is skipped.  With RCCL the three parts are
+// enqueued back to back on the context's stream; in external mode the
+// library stops after *_local so that the caller can reduce the buffer.
+
+static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     free_training(c);
     c->vocab_size = vocab_size;
     c->n_target = vocab_size - 256;
@@ -406,19 +459,27 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     const uint64_t n = c->inert ? 0 : c->n_bytes;
     c->n_slots = std::max<uint64_t>(round_up(n, kTile), kTile);
     c->cap_slots = c->n_slots;
+    if (c->n_slots / kTile > 0x0FFFFFF0ull) { mbpe_host::set_last_error("corpus shard too large"); return MBPE_ERR_ARG; }
     c->n_tiles = (uint32_t)(c->n_slots / kTile);
+    c->hdr_words = exchange_header_words(c->n_ranks);
     for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->tok[i], c->cap_slots * 2));
     HIPCHK(hipMalloc(&c->sums, (size_t)c->n_tiles * sizeof(TileSum)));
     HIPCHK(hipMalloc(&c->side, (size_t)c->n_tiles * sizeof(TileSum)));
     HIPCHK(hipMalloc(&c->chg, ((size_t)c->n_tiles / 32 + 2) * 4));
     HIPCHK(hipMemsetAsync(c->chg, 0, ((size_t)c->n_tiles / 32 + 2) * 4, c->stream));
     HIPCHK(hipMalloc(&c->offsets, (size_t)c->n_tiles * 8));
-    HIPCHK(hipMalloc(&c->bp, 65536 * 4));
+    const size_t xb_words = (size_t)c->hdr_words + 2 * (size_t)vocab_size + 8;
+    const size_t xb0_words = 65536 + (size_t)c->hdr_words;
+    HIPCHK(hipMalloc(&c->xb, xb_words * 4));
+    HIPCHK(hipMalloc(&c->xb0, xb0_words * 4));
+    HIPCHK(hipMemsetAsync(c->xb, 0, xb_words * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->xb0, 0, xb0_words * 4, c->stream));
+    c->LR = c->xb + c->hdr_words;
+    c->bp = nullptr;   // the byte-pair table lives at the front of xb0
+    HIPCHK(hipMalloc(&c->d_left, sizeof(RankEdge)));
+    HIPCHK(hipMalloc(&c->d_right, sizeof(RankEdge)));
     HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
     HIPCHK(hipMalloc(&c->best, ((size_t)c->n_target + 2) * 8));
-    HIPCHK(hipMalloc(&c->L, ((size_t)vocab_size * 2 + 8) * 4));
-    c->R = c->L + vocab_size;
-    HIPCHK(hipMemsetAsync(c->bp, 0, 65536 * 4, c->stream));
     {
         DevCtl init = {};
         init.n_live = n;         // every corpus byte starts as one live token
@@ -426,7 +487,6 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
         HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl, sizeof(DevCtl), hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(hipMemsetAsync(c->best, 0, ((size_t)c->n_target + 2) * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->L, 0, ((size_t)vocab_size * 2 + 8) * 4, c->stream));
 
     uint64_t want = 65536 + 2 * batch_headroom(c, (uint32_t)c->opt_batch);
     want = std::min<uint64_t>(want, table_cap_limit(c));
@@ -434,14 +494,28 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     if (rc != MBPE_OK) return rc;
 
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    if (n >= 2) launch_pair_count_u8(c->stream, c->d_text, n, c->d_endmask, c->bp, c->n_cus);
-    launch_table_init(c->stream, c->bp, c->tab, c->ctl);
+    if (n >= 2) launch_pair_count_u8(c->stream, c->d_text, n, c->d_endmask, c->xb0, c->n_cus);
     c->cur = 0;
     launch_widen(c->stream, c->d_text, n, c->d_endmask, c->tok[0], c->n_slots);
     launch_summarize(c->stream, c->tok[0], c->sums, c->n_tiles, c->n_cus);
+    if (c->n_ranks > 1) {
+        uint32_t *hdr = c->xb0 + 65536;
+        launch_rank_edge(c->stream, c->sums, c->n_tiles, reinterpret_cast<RankEdge *>(hdr + 2) + c->rank, c->ctl, hdr);
+    }
+    return MBPE_OK;
+}
+
+static int begin_finish(mbpe_ctx *c) {
+    const uint32_t endbit = c->chunked ? kEndBit : 0;
+    if (c->n_ranks > 1) {
+        uint32_t *hdr = c->xb0 + 65536;
+        launch_boundary_pairs(c->stream, c->xb0, hdr, c->n_ranks, endbit);
+        launch_compose_edges(c->stream, hdr, c->rank, c->n_ranks, c->d_left, c->d_right);
+    }
+    launch_table_init(c->stream, c->xb0, c->tab, c->ctl);
     launch_argmax(c->stream, c->tab, c->ctl, c->best);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
-    rc = sync_ctl(c);
+    int rc = sync_ctl(c);
     if (rc != MBPE_OK) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventElapsedTime(&c->stats.ms_begin, c->ev0, c->ev1));
@@ -453,20 +527,100 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     return MBPE_OK;
 }
 
+static void step_local(mbpe_ctx *c, int ev_slot) {
+    const uint32_t endbit = c->chunked ? kEndBit : 0;
+    const uint32_t X = 256 + c->k;
+    const bool multi = c->n_ranks > 1;
+    if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
+    launch_merge(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best + c->k, X, endbit, c->LR,
+                 c->ctl, multi ? c->d_left : nullptr, multi ? c->d_right : nullptr, c->n_cus);
+    if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
+    if (multi) {
+        launch_patch_sums(c->stream, c->best + c->k, c->sums, c->side, c->chg, c->n_tiles);
+        launch_rank_edge(c->stream, c->sums, c->n_tiles, reinterpret_cast<RankEdge *>(c->xb + 2) + c->rank, c->ctl,
+                         c->xb);
+    }
+}
+
+static void step_finish(mbpe_ctx *c) {
+    const uint32_t X = 256 + c->k;
+    const bool multi = c->n_ranks > 1;
+    launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->LR, multi ? c->xb : nullptr, c->sums, c->side,
+                 c->chg, c->n_tiles);
+    if (multi) launch_compose_edges(c->stream, c->xb, c->rank, c->n_ranks, c->d_left, c->d_right);
+    launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1);
+    c->k++;
+}
+
+// words of xb a merge has to exchange: header + LR entries of the ids that exist (x < X)
+static size_t step_exchange_words(const mbpe_ctx *c) { return (size_t)c->hdr_words + 2 * (size_t)(256 + c->k); }
+
+static int comm_allreduce(mbpe_ctx *c, uint32_t *buf, size_t count);   // RCCL (below)
+
+// housekeeping between batches: errors, holes, table headroom (h_ctl must be current)
+static int after_batch(mbpe_ctx *c) {
+    c->n_valid = c->k;
+    if (c->opt_compact_den > 0 && c->h_ctl.removed_total > 0 &&
+        c->h_ctl.removed_total * (uint64_t)c->opt_compact_den >= c->n_slots) {
+        int rc = do_compact(c);
+        if (rc != MBPE_OK) return rc;
+    }
+    return MBPE_OK;
+}
+
+static int before_batch(mbpe_ctx *c, uint32_t batch) {
+    if ((uint64_t)c->h_ctl.n_entries + batch_headroom(c, batch) > c->tab.ecap)
+        return grow_table(c, ((uint64_t)c->h_ctl.n_entries + batch_headroom(c, batch)) * 2);
+    return MBPE_OK;
+}
+
+int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
+    if (!c) return MBPE_ERR_ARG;
+    if (!c->loaded) { mbpe_host::set_last_error("mbpe_train_begin: no corpus loaded"); return MBPE_ERR_STATE; }
+    if (vocab_size < 256) { mbpe_host::set_last_error("vocab_size must be >= 256"); return MBPE_ERR_ARG; }
+    const uint32_t vmax = c->chunked ? MBPE_MAX_VOCAB_CHUNKED : MBPE_MAX_VOCAB_BASIC;
+    if (vocab_size > vmax) {
+        mbpe_host::set_last_error("vocab_size exceeds the 16-bit slot format (" + std::to_string(vmax) + ")");
+        return MBPE_ERR_VOCAB;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = begin_local(c, vocab_size);
+    if (rc != MBPE_OK) return rc;
+    if (c->n_ranks > 1) {
+        if (c->comm_external) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->pending = 1;
+            return MBPE_NEED_EXCHANGE;
+        }
+        rc = comm_allreduce(c, c->xb0, 65536 + (size_t)c->hdr_words);
+        if (rc != MBPE_OK) return rc;
+    }
+    return begin_finish(c);
+}
+
 int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
     if (steps_done_out) *steps_done_out = 0;
     if (!c) return MBPE_ERR_ARG;
     if (!c->begun) { mbpe_host::set_last_error("mbpe_train_steps before mbpe_train_begin"); return MBPE_ERR_STATE; }
+    if (c->pending) { mbpe_host::set_last_error("an exchange is pending: call mbpe_comm_exchange_done"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
+    if (c->n_ranks > 1 && c->comm_external) {
+        // one merge per round trip: local part now, the rest in mbpe_comm_exchange_done
+        if (n_steps == 0 || c->k >= c->n_target || c->exhausted) return MBPE_OK;
+        int rc = before_batch(c, 1);
+        if (rc != MBPE_OK) return rc;
+        c->pending_steps = std::min<uint32_t>(n_steps, c->n_target - c->k);
+        c->pending_done = 0;
+        step_local(c, -1);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->pending = 2;
+        return MBPE_NEED_EXCHANGE;
+    }
     uint32_t done = 0;
-    const uint32_t endbit = c->chunked ? kEndBit : 0;
     while (done < n_steps && c->k < c->n_target && !c->exhausted) {
         uint32_t batch = std::min<uint32_t>({(uint32_t)c->opt_batch, n_steps - done, c->n_target - c->k});
-        // pair-table headroom for this batch (h_ctl.n_entries is exact here)
-        if ((uint64_t)c->h_ctl.n_entries + batch_headroom(c, batch) > c->tab.ecap) {
-            int rc = grow_table(c, ((uint64_t)c->h_ctl.n_entries + batch_headroom(c, batch)) * 2);
-            if (rc != MBPE_OK) return rc;
-        }
+        int rc = before_batch(c, batch);   // pair-table headroom (h_ctl.n_entries is exact here)
+        if (rc != MBPE_OK) return rc;
         if (c->opt_time_kernels) {
             while (c->kev.size() < 2ull * batch) {
                 hipEvent_t e;
@@ -476,18 +630,15 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
         }
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         for (uint32_t i = 0; i < batch; ++i) {
-            const uint32_t X = 256 + c->k;
-            if (c->opt_time_kernels) HIPCHK(hipEventRecord(c->kev[2 * i], c->stream));
-            launch_merge(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best + c->k, X, endbit,
-                         c->L, c->R, c->ctl, nullptr, nullptr, c->n_cus);
-            if (c->opt_time_kernels) HIPCHK(hipEventRecord(c->kev[2 * i + 1], c->stream));
-            launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->L, c->R, nullptr, c->sums, c->side, c->chg,
-                         c->n_tiles);
-            launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1);
-            c->k++;
+            step_local(c, c->opt_time_kernels ? (int)i : -1);
+            if (c->n_ranks > 1) {
+                rc = comm_allreduce(c, c->xb, step_exchange_words(c));
+                if (rc != MBPE_OK) return rc;
+            }
+            step_finish(c);
         }
         HIPCHK(hipEventRecord(c->ev1, c->stream));
-        int rc = sync_ctl(c);
+        rc = sync_ctl(c);
         if (rc != MBPE_OK) return rc;
         HIPCHK(hipGetLastError());
         float ms = 0;
@@ -502,15 +653,49 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
             }
         }
         done += batch;
-        c->n_valid = c->k;
-        if (c->opt_compact_den > 0 && c->h_ctl.removed_total * (uint64_t)c->opt_compact_den >= c->n_slots &&
-            c->h_ctl.removed_total > 0) {
-            rc = do_compact(c);
-            if (rc != MBPE_OK) return rc;
-        }
+        rc = after_batch(c);
+        if (rc != MBPE_OK) return rc;
     }
     if (steps_done_out) *steps_done_out = done;
     return MBPE_OK;
+}
+
+int mbpe_comm_exchange_buffer(mbpe_ctx *c, void **dev_ptr_out, uint64_t *n_u32_out) {
+    if (!c || !dev_ptr_out || !n_u32_out) return MBPE_ERR_ARG;
+    if (c->pending == 1) { *dev_ptr_out = c->xb0; *n_u32_out = 65536 + (uint64_t)c->hdr_words; return MBPE_OK; }
+    if (c->pending == 2) { *dev_ptr_out = c->xb; *n_u32_out = step_exchange_words(c); return MBPE_OK; }
+    mbpe_host::set_last_error("no exchange pending");
+    return MBPE_ERR_STATE;
+}
+
+int mbpe_comm_exchange_done(mbpe_ctx *c) {
+    if (!c) return MBPE_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->pending == 1) {
+        c->pending = 0;
+        return begin_finish(c);
+    }
+    if (c->pending == 2) {
+        c->pending = 0;
+        step_finish(c);
+        int rc = sync_ctl(c);
+        if (rc != MBPE_OK) return rc;
+        HIPCHK(hipGetLastError());
+        c->pending_done++;
+        rc = after_batch(c);
+        if (rc != MBPE_OK) return rc;
+        if (c->pending_done < c->pending_steps && c->k < c->n_target) {
+            rc = before_batch(c, 1);
+            if (rc != MBPE_OK) return rc;
+            step_local(c, -1);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->pending = 2;
+            return MBPE_NEED_EXCHANGE;
+        }
+        return MBPE_OK;
+    }
+    mbpe_host::set_last_error("no exchange pending");
+    return MBPE_ERR_STATE;
 }
 
 int mbpe_train_result(mbpe_ctx *c, uint32_t *merges_out, int32_t *counts_out, uint32_t cap_merges,
@@ -615,14 +800,65 @@ int mbpe_compact(mbpe_ctx *c) {
     return do_compact(c);
 }
 
-int mbpe_comm_unique_id(uint8_t *) {
-    mbpe_host::set_last_error("multi-GPU support not built yet");
-    return MBPE_ERR_COMM;
+// ---- multi-GPU transport ------------------------------------------------------
+
+static int comm_allreduce(mbpe_ctx *c, uint32_t *buf, size_t count) {
+    Rccl &r = rccl();
+    if (!r.ok || !c->nccl_comm) { mbpe_host::set_last_error("RCCL communicator not initialised"); return MBPE_ERR_COMM; }
+    int rc = r.AllReduce(buf, buf, count, (int)ncclUint32, (int)ncclSum, c->nccl_comm, c->stream);
+    if (rc != 0) {
+        mbpe_host::set_last_error(std::string("ncclAllReduce: ") + r.GetErrorString(rc));
+        return MBPE_ERR_COMM;
+    }
+    return MBPE_OK;
 }
 
-int mbpe_comm_init(mbpe_ctx *, const uint8_t *, int, int) {
-    mbpe_host::set_last_error("multi-GPU support not built yet");
-    return MBPE_ERR_COMM;
+int mbpe_comm_unique_id(uint8_t *id_out) {
+    if (!id_out) return MBPE_ERR_ARG;
+    Rccl &r = rccl();
+    if (!r.ok) { mbpe_host::set_last_error(r.why); return MBPE_ERR_COMM; }
+    static_assert(sizeof(ncclUniqueId) == MBPE_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    int rc = r.GetUniqueId(&id);
+    if (rc != 0) { mbpe_host::set_last_error(std::string("ncclGetUniqueId: ") + r.GetErrorString(rc)); return MBPE_ERR_COMM; }
+    memcpy(id_out, &id, sizeof(id));
+    return MBPE_OK;
+}
+
+int mbpe_comm_init(mbpe_ctx *c, const uint8_t *id, int rank, int n_ranks) {
+    if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+        mbpe_host::set_last_error("mbpe_comm_init: bad argument");
+        return MBPE_ERR_ARG;
+    }
+    if (c->begun || c->pending) { mbpe_host::set_last_error("mbpe_comm_init after mbpe_train_begin"); return MBPE_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    Rccl &r = rccl();
+    if (!r.ok) { mbpe_host::set_last_error(r.why); return MBPE_ERR_COMM; }
+    if (c->nccl_comm) { r.CommDestroy(c->nccl_comm); c->nccl_comm = nullptr; }
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    int rc = r.CommInitRank(&c->nccl_comm, n_ranks, uid, rank);
+    if (rc != 0) {
+        mbpe_host::set_last_error(std::string("ncclCommInitRank: ") + r.GetErrorString(rc));
+        c->nccl_comm = nullptr;
+        return MBPE_ERR_COMM;
+    }
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    c->comm_external = false;
+    return MBPE_OK;
+}
+
+int mbpe_comm_init_external(mbpe_ctx *c, int rank, int n_ranks) {
+    if (!c || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+        mbpe_host::set_last_error("mbpe_comm_init_external: bad argument");
+        return MBPE_ERR_ARG;
+    }
+    if (c->begun || c->pending) { mbpe_host::set_last_error("mbpe_comm_init_external after mbpe_train_begin"); return MBPE_ERR_STATE; }
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    c->comm_external = true;
+    return MBPE_OK;
 }
 
 }  // extern "C"

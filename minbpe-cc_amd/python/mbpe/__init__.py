@@ -13,6 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__fil
 LIB_PATH = os.environ.get("MBPE_LIB") or os.path.join(_PKG_DIR, "libmbpe.so")
 
 OK = 0
+NEED_EXCHANGE = 1
 ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_VOCAB, ERR_STATE = -1, -2, -3, -4, -5
 ERR_OOM, ERR_REGEX, ERR_SPLIT_GAP, ERR_COMM, ERR_OVERFLOW, ERR_IO = -6, -7, -8, -9, -10, -11
 COMM_ID_BYTES = 128
@@ -22,7 +23,8 @@ EXPORTS = [
     "mbpe_last_error", "mbpe_version", "mbpe_create", "mbpe_destroy", "mbpe_load_corpus",
     "mbpe_pair_count_u8", "mbpe_train_begin", "mbpe_train_steps", "mbpe_train_result",
     "mbpe_train_lexical", "mbpe_get_stats", "mbpe_get_stream", "mbpe_get_pairs", "mbpe_compact",
-    "mbpe_set_option", "mbpe_comm_unique_id", "mbpe_comm_init", "mbpe_presplit",
+    "mbpe_set_option", "mbpe_comm_unique_id", "mbpe_comm_init", "mbpe_comm_init_external",
+    "mbpe_comm_exchange_buffer", "mbpe_comm_exchange_done", "mbpe_presplit",
     "mbpe_split_count", "mbpe_split_offsets", "mbpe_split_free", "mbpe_split_pattern",
 ]
 
@@ -75,6 +77,9 @@ def lib():
     L.mbpe_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     L.mbpe_comm_unique_id.argtypes = [vp]
     L.mbpe_comm_init.argtypes = [vp, vp, i32, i32]
+    L.mbpe_comm_init_external.argtypes = [vp, i32, i32]
+    L.mbpe_comm_exchange_buffer.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    L.mbpe_comm_exchange_done.argtypes = [vp]
     L.mbpe_presplit.argtypes = [ctypes.c_char_p, vp, u64, ctypes.POINTER(vp)]
     L.mbpe_split_count.argtypes = [vp]
     L.mbpe_split_count.restype = u64
@@ -89,8 +94,9 @@ def lib():
 
 
 def _check(rc):
-    if rc != OK:
+    if rc < 0:
         raise MbpeError(rc, lib().mbpe_last_error().decode("utf-8", "replace"))
+    return rc
 
 
 def _u8(data):
@@ -170,13 +176,31 @@ class Trainer:
         return table
 
     def train_begin(self, vocab_size):
-        _check(lib().mbpe_train_begin(self._h, vocab_size))
+        """Returns NEED_EXCHANGE in external-transport mode, else OK."""
         self.vocab_size = vocab_size
+        return _check(lib().mbpe_train_begin(self._h, vocab_size))
 
     def train_steps(self, n_steps):
+        """Returns the number of merges made (external-transport mode: NEED_EXCHANGE / OK code)."""
         done = ctypes.c_uint32()
-        _check(lib().mbpe_train_steps(self._h, n_steps, ctypes.byref(done)))
-        return done.value
+        rc = _check(lib().mbpe_train_steps(self._h, n_steps, ctypes.byref(done)))
+        return rc if self._external else done.value
+
+    _external = False
+
+    def comm_init_external(self, rank, n_ranks):
+        _check(lib().mbpe_comm_init_external(self._h, rank, n_ranks))
+        self._external = n_ranks > 1
+
+    def exchange_buffer(self):
+        """(device pointer, number of u32) of the buffer to sum-all-reduce across ranks."""
+        p = ctypes.c_void_p()
+        n = ctypes.c_uint64()
+        _check(lib().mbpe_comm_exchange_buffer(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def exchange_done(self):
+        return _check(lib().mbpe_comm_exchange_done(self._h))
 
     def train_result(self):
         cap = max(self.vocab_size - 256, 1)

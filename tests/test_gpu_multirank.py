@@ -1,0 +1,132 @@
+"""GPU tests of the sharded (multi-GPU) algorithm on ONE GPU: several contexts,
+one per "rank", run the real kernels on their shard of the corpus; the test
+plays the collective (sum of the exchange buffers) through the external-transport
+C-ABI.  Everything except the ncclAllReduce call itself is the production path.
+Results must equal the single-rank oracle on the whole corpus."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import mbpe
+import oracle as O
+from conftest import read_data
+
+pytestmark = pytest.mark.gpu
+
+_hip = None
+
+
+def hip():
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    return _hip
+
+
+def _allreduce(trainers):
+    bufs = [t.exchange_buffer() for t in trainers]
+    n = bufs[0][1]
+    assert all(b[1] == n for b in bufs)
+    total = np.zeros(n, dtype=np.uint32)
+    tmp = np.zeros(n, dtype=np.uint32)
+    for ptr, _ in bufs:
+        assert hip().hipMemcpy(tmp.ctypes.data, ptr, n * 4, 2) == 0      # D2H
+        total += tmp
+    for ptr, _ in bufs:
+        assert hip().hipMemcpy(ptr, total.ctypes.data, n * 4, 1) == 0    # H2D
+
+
+def _train_sharded(data, cuts, vocab, chunk_off=None):
+    data = np.frombuffer(bytes(data), dtype=np.uint8)
+    bounds = [0] + list(cuts) + [len(data)]
+    R = len(bounds) - 1
+    trainers = [mbpe.Trainer(0) for _ in range(R)]
+    try:
+        for r, t in enumerate(trainers):
+            lo, hi = bounds[r], bounds[r + 1]
+            t.comm_init_external(r, R)
+            off = None
+            if chunk_off is not None:
+                sel = chunk_off[(chunk_off >= lo) & (chunk_off <= hi)]
+                assert sel[0] == lo and sel[-1] == hi, "shards must hold whole chunks"
+                off = (sel - lo).astype(np.uint64)
+            t.load_corpus(data[lo:hi], off)
+        codes = [t.train_begin(vocab) for t in trainers]
+        assert all(c == mbpe.NEED_EXCHANGE for c in codes)
+        _allreduce(trainers)
+        assert all(t.exchange_done() == mbpe.OK for t in trainers)
+        codes = [t.train_steps(vocab - 256) for t in trainers]
+        while codes[0] == mbpe.NEED_EXCHANGE:
+            assert all(c == mbpe.NEED_EXCHANGE for c in codes)
+            _allreduce(trainers)
+            codes = [t.exchange_done() for t in trainers]
+        assert all(c == mbpe.OK for c in codes)
+        results = [t.train_result() for t in trainers]
+        streams = [t.stream()[0] for t in trainers]
+        tables = [t.pairs_dict() for t in trainers]
+        return results, streams, tables
+    finally:
+        for t in trainers:
+            t.close()
+
+
+def _check(data, cuts, vocab, chunk_off=None):
+    want_m, want_c = O.train(data, vocab, chunk_off)
+    results, streams, tables = _train_sharded(data, cuts, vocab, chunk_off)
+    for m, c in results:                      # every rank takes the same decisions
+        assert m.tolist() == want_m.tolist()
+        assert c.tolist() == want_c.tolist()
+    st = O.State(data, chunk_off)
+    for i, (a, b) in enumerate(want_m):
+        st.merge(int(a), int(b), 256 + i)
+    assert np.array_equal(np.concatenate(streams), st.stream()[0])
+    want_tab = {k: v for k, v in st.table_dict().items() if v}
+    for tab in tables:                        # replicated pair table
+        assert {k: v for k, v in tab.items() if v} == want_tab
+
+
+def test_two_ranks_random_bytes():
+    data = O.splitmix64_bytes(3, 40000).tobytes()
+    _check(data, [17777], 256 + 60)
+
+
+@pytest.mark.parametrize("R", [2, 3, 4])
+def test_small_alphabet_many_cuts(R):
+    rng = np.random.default_rng(R)
+    for _ in range(3):
+        n = int(rng.integers(50, 5000))
+        data = rng.integers(97, 97 + int(rng.integers(1, 4)), size=n, dtype=np.uint8).tobytes()
+        cuts = sorted(set(int(x) for x in rng.integers(1, n, size=R - 1)))
+        while len(cuts) < R - 1:
+            cuts = sorted(set(cuts + [int(rng.integers(1, n))]))
+        _check(data, cuts, 256 + 30)
+
+
+def test_runs_and_touching_matches_across_the_cut():
+    # "abab" cut inside a match and between matches; runs of one byte over the cut
+    _check(b"xy" + b"ab" * 301 + b"z", [2 + 301], 256 + 12)        # cut between a and b
+    _check(b"xy" + b"ab" * 301 + b"z", [2 + 300], 256 + 12)        # cut between two matches
+    _check(b"q" + b"a" * 1001 + b"r" + b"a" * 700, [400, 1100], 256 + 14)
+    _check(b"a" * 1024, [512], 256 + 12)
+    _check(b"a" * 1025, [1, 1024], 256 + 12)
+
+
+def test_empty_and_tiny_shards():
+    data = b"abcabcabcabcabcabc"
+    _check(data, [1], 256 + 6)
+    _check(data, [len(data) - 1], 256 + 6)
+    _check(data, [5, 6, 7], 256 + 6)
+
+
+def test_chunked_shards_text():
+    data = read_data("taylorswift.txt")[:50000]
+    off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data)
+    cuts = [int(off[len(off) // 3]), int(off[2 * len(off) // 3])]
+    _check(data, cuts, 256 + 40, off)
+
+
+def test_text_three_ranks():
+    data = read_data("shakespeare.txt")[:200000]
+    _check(data, [65536, 131073], 256 + 64)
