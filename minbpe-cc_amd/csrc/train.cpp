@@ -170,6 +170,7 @@ struct mbpe_ctx {
     int64_t opt_batch = 64;
     int64_t opt_use_graph = 1;
     int64_t opt_time_kernels = 0;   // HIP events around every merge kernel (bench.py)
+    int64_t opt_force_exchange = 0; // run the multi-rank path (edges, exchange) even with one rank
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
 
     mbpe_stats stats = {};
@@ -326,6 +327,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "batch") c->opt_batch = std::max<int64_t>(1, value);
     else if (n == "use_graph") c->opt_use_graph = value;
     else if (n == "time_kernels") c->opt_time_kernels = value;
+    else if (n == "force_exchange") c->opt_force_exchange = value;
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
 }
@@ -448,6 +450,8 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
 // enqueued back to back on the context's stream; in external mode the
 // library stops after *_local so that the caller can reduce the buffer.
 
+static inline bool is_multi(const mbpe_ctx *c) { return c->n_ranks > 1 || c->opt_force_exchange; }
+
 static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     free_training(c);
     c->vocab_size = vocab_size;
@@ -498,7 +502,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     c->cur = 0;
     launch_widen(c->stream, c->d_text, n, c->d_endmask, c->tok[0], c->n_slots);
     launch_summarize(c->stream, c->tok[0], c->sums, c->n_tiles, c->n_cus);
-    if (c->n_ranks > 1) {
+    if (is_multi(c)) {
         uint32_t *hdr = c->xb0 + 65536;
         launch_rank_edge(c->stream, c->sums, c->n_tiles, reinterpret_cast<RankEdge *>(hdr + 2) + c->rank, c->ctl, hdr);
     }
@@ -507,7 +511,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
 
 static int begin_finish(mbpe_ctx *c) {
     const uint32_t endbit = c->chunked ? kEndBit : 0;
-    if (c->n_ranks > 1) {
+    if (is_multi(c)) {
         uint32_t *hdr = c->xb0 + 65536;
         launch_boundary_pairs(c->stream, c->xb0, hdr, c->n_ranks, endbit);
         launch_compose_edges(c->stream, hdr, c->rank, c->n_ranks, c->d_left, c->d_right);
@@ -530,7 +534,7 @@ static int begin_finish(mbpe_ctx *c) {
 static void step_local(mbpe_ctx *c, int ev_slot) {
     const uint32_t endbit = c->chunked ? kEndBit : 0;
     const uint32_t X = 256 + c->k;
-    const bool multi = c->n_ranks > 1;
+    const bool multi = is_multi(c);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     launch_merge(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best + c->k, X, endbit, c->LR,
                  c->ctl, multi ? c->d_left : nullptr, multi ? c->d_right : nullptr, c->n_cus);
@@ -544,7 +548,7 @@ static void step_local(mbpe_ctx *c, int ev_slot) {
 
 static void step_finish(mbpe_ctx *c) {
     const uint32_t X = 256 + c->k;
-    const bool multi = c->n_ranks > 1;
+    const bool multi = is_multi(c);
     launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->LR, multi ? c->xb : nullptr, c->sums, c->side,
                  c->chg, c->n_tiles);
     if (multi) launch_compose_edges(c->stream, c->xb, c->rank, c->n_ranks, c->d_left, c->d_right);
@@ -586,7 +590,7 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(hipSetDevice(c->device));
     int rc = begin_local(c, vocab_size);
     if (rc != MBPE_OK) return rc;
-    if (c->n_ranks > 1) {
+    if (is_multi(c)) {
         if (c->comm_external) {
             HIPCHK(hipStreamSynchronize(c->stream));
             c->pending = 1;
@@ -604,7 +608,7 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
     if (!c->begun) { mbpe_host::set_last_error("mbpe_train_steps before mbpe_train_begin"); return MBPE_ERR_STATE; }
     if (c->pending) { mbpe_host::set_last_error("an exchange is pending: call mbpe_comm_exchange_done"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
-    if (c->n_ranks > 1 && c->comm_external) {
+    if (is_multi(c) && c->comm_external) {
         // one merge per round trip: local part now, the rest in mbpe_comm_exchange_done
         if (n_steps == 0 || c->k >= c->n_target || c->exhausted) return MBPE_OK;
         int rc = before_batch(c, 1);
@@ -631,7 +635,7 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         for (uint32_t i = 0; i < batch; ++i) {
             step_local(c, c->opt_time_kernels ? (int)i : -1);
-            if (c->n_ranks > 1) {
+            if (is_multi(c)) {
                 rc = comm_allreduce(c, c->xb, step_exchange_words(c));
                 if (rc != MBPE_OK) return rc;
             }

@@ -130,3 +130,19 @@ def test_chunked_shards_text():
 def test_text_three_ranks():
     data = read_data("shakespeare.txt")[:200000]
     _check(data, [65536, 131073], 256 + 64)
+
+
+def test_rccl_single_rank_communicator():
+    # A 1-rank RCCL communicator through the production transport: exercises the
+    # run-time RCCL binding, ncclCommInitRank and the per-merge ncclAllReduce on
+    # the context's stream (the 8-GPU run itself is the driver's).
+    data = O.splitmix64_bytes(12, 100000).tobytes()
+    want_m, want_c = O.train(data, 256 + 80)
+    with mbpe.Trainer(0) as t:
+        t.comm_init(mbpe.comm_unique_id(), 0, 1)
+        t.set_option("force_exchange", 1)
+        t.load_corpus(np.frombuffer(data, dtype=np.uint8))
+        assert t.train_begin(256 + 80) == mbpe.OK
+        assert t.train_steps(80) == 80
+        m, c = t.train_result()
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
