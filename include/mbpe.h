@@ -164,6 +164,7 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *   "compact_den"   compact when holes * den >= slots (default 8; 0 = never)
  *   "batch"         merges per host round trip (default 64)
  *   "use_graph"     1 = replay merges from a captured hipGraph (default 1)
+ *   "hier_argmax"   -1 auto / 0 scan every entry / 1 walk the block bounds
  *   "force_exchange" 1 = take the multi-rank path (rank edges, exchange) even
  *                   with a single rank (tests the RCCL binding on one GPU)
  *   "time_kernels"  1 = bracket every merge kernel with HIP events on the

@@ -100,6 +100,10 @@ __device__ void table_add(const PairTable &t, DevCtl *ctl, uint32_t key, int32_t
                 t.hidx[h] = idx;
                 t.ekey[idx] = key;
                 t.ecnt[idx] = delta;
+                // upper bounds for the hierarchical argmax (counts only fall after insertion)
+                const unsigned long long p = pack_best(delta, key);
+                atomicMax(&t.bmax[idx >> kBlockShift], p);
+                atomicMax(&t.smax[idx >> (2 * kBlockShift)], p);
                 return;
             }
             if (prev == key) {  // cannot happen by construction; keep the table sane anyway
@@ -464,6 +468,95 @@ __global__ __launch_bounds__(kArgmaxThreads) void k_argmax(PairTable t, const De
 #pragma unroll
         for (int k = 1; k < kArgmaxThreads / kWave; ++k) b = wbest[k] > b ? wbest[k] : b;
         if (b) atomicMax(best, b);
+    }
+}
+
+// Hierarchical argmax for large tables.  A count never rises after its pair was
+// inserted (a merge only lowers existing pairs and inserts pairs of the new
+// token), so per-block maxima recorded at insertion stay valid UPPER bounds:
+//   bmax[B] >= max packed value of entries [1024 B, 1024 B + 1024)
+//   smax[S] >= max of bmax[1024 S ..]
+// One workgroup repeatedly takes the block with the highest bound, recomputes
+// its true maximum (tightening both bounds) and stops as soon as that true
+// maximum is not below any other bound.  Typically two rounds per merge (the
+// first one hits the block of the pair that was just merged away), whatever
+// the table size.
+constexpr int kHierThreads = 1024;
+
+struct Top2 { unsigned long long v1, v2; uint32_t i1; };
+
+__device__ __forceinline__ Top2 top2_merge(Top2 a, unsigned long long bv1, unsigned long long bv2, uint32_t bi1) {
+    Top2 r;
+    if (bv1 > a.v1) { r.v1 = bv1; r.i1 = bi1; r.v2 = a.v1 > bv2 ? a.v1 : bv2; }
+    else { r.v1 = a.v1; r.i1 = a.i1; r.v2 = bv1 > a.v2 ? bv1 : a.v2; }
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int d) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, d, kWave), hi = __shfl_xor((uint32_t)(v >> 32), d, kWave);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// largest and second largest of one value per thread over the workgroup (all threads get the result)
+__device__ Top2 block_top2(unsigned long long v, uint32_t idx, Top2 *sh) {
+    Top2 t = {v, 0ull, idx};
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        const unsigned long long o1 = shfl_xor_u64(t.v1, d), o2 = shfl_xor_u64(t.v2, d);
+        const uint32_t oi = __shfl_xor(t.i1, d, kWave);
+        t = top2_merge(t, o1, o2, oi);
+    }
+    __syncthreads();                       // sh may still be read from the previous call
+    if (lane_id() == 0) sh[threadIdx.x / kWave] = t;
+    __syncthreads();
+    Top2 r = sh[0];
+#pragma unroll
+    for (int k = 1; k < kHierThreads / kWave; ++k) r = top2_merge(r, sh[k].v1, sh[k].v2, sh[k].i1);
+    return r;
+}
+
+__global__ __launch_bounds__(kHierThreads) void k_argmax_hier(PairTable t, const DevCtl *ctl,
+                                                              unsigned long long *best) {
+    __shared__ Top2 sh[kHierThreads / kWave];
+    const uint32_t n = ctl->n_entries < t.ecap ? ctl->n_entries : t.ecap;
+    if (n == 0) return;
+    const uint32_t n_blocks = (n + kBlockSize - 1) >> kBlockShift;
+    const uint32_t n_super = (n_blocks + kBlockSize - 1) >> kBlockShift;
+    const uint32_t tid = threadIdx.x;
+    // bounds are re-read after this workgroup rewrote them: agent-scope relaxed
+    // accesses (sc1) bypass the CU's L1
+    auto ld = [](const unsigned long long *p) {
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    for (int round = 0; round < 1 << 20; ++round) {   // terminates: every round lowers one bound
+        // best and second-best super-block bound (n_super <= 1024: the table is capped at 2^30 entries)
+        const Top2 ts = block_top2(tid < n_super ? ld(&t.smax[tid]) : 0ull, tid, sh);
+        if (ts.v1 == 0ull) return;
+        const uint32_t S = ts.i1;
+        // best and second-best block bound inside S
+        const uint32_t bidx = (S << kBlockShift) + tid;
+        const Top2 tb = block_top2(bidx < n_blocks ? ld(&t.bmax[bidx]) : 0ull, bidx, sh);
+        const uint32_t B = tb.i1;
+        // true maximum of block B
+        const uint32_t e = (B << kBlockShift) + tid;
+        unsigned long long p = 0;
+        if (e < n) {
+            const int32_t c = t.ecnt[e];
+            p = pack_best(c < 0 ? 0 : c, t.ekey[e]);
+        }
+        const Top2 te = block_top2(p, e, sh);
+        const unsigned long long truth = te.v1;
+        const unsigned long long s_bound = truth > tb.v2 ? truth : tb.v2;
+        if (tid == 0) {
+            __hip_atomic_store(&t.bmax[B], truth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&t.smax[S], s_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // done when the true maximum is not below any other bound
+        if (truth >= tb.v2 && truth >= ts.v2) {
+            if (tid == 0 && truth) atomicMax(best, truth);
+            return;
+        }
+        __syncthreads();
     }
 }
 
@@ -1048,7 +1141,11 @@ void launch_table_rehash(hipStream_t s, PairTable t, DevCtl *ctl) {
     hipLaunchKernelGGL(k_table_rehash, dim3((t.ecap + 255) / 256), dim3(256), 0, s, t, ctl);
 }
 
-void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best) {
+void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best, bool hierarchical) {
+    if (hierarchical) {
+        hipLaunchKernelGGL(k_argmax_hier, dim3(1), dim3(kHierThreads), 0, s, t, ctl, best);
+        return;
+    }
     int blocks = blocks_for(t.ecap, kArgmaxThreads * 4, 1024);
     hipLaunchKernelGGL(k_argmax, dim3(blocks), dim3(kArgmaxThreads), 0, s, t, ctl, best);
 }

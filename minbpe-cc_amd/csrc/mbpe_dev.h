@@ -50,11 +50,16 @@ struct RankEdge {
 // pair whose count returned to 0 is still a candidate (SURVEY.md 8-S rule 4).
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
 
+constexpr int kBlockShift = 10;                 // argmax hierarchy: 1024 entries per block,
+constexpr uint32_t kBlockSize = 1u << kBlockShift;   // 1024 blocks per super-block
+
 struct PairTable {
     uint32_t *hkey;      // [hcap] kEmptyKey when free
     uint32_t *hidx;      // [hcap] index into ekey/ecnt
     uint32_t *ekey;      // [ecap]
     int32_t  *ecnt;      // [ecap]
+    unsigned long long *bmax;   // [ecap / 1024 + 1] upper bound of packed (count, ~key) per block
+    unsigned long long *smax;   // [ecap / 1024^2 + 1] upper bound per super-block
     uint32_t  hmask;     // hcap - 1
     uint32_t  ecap;
 };
@@ -109,7 +114,8 @@ void launch_table_init(hipStream_t s, const uint32_t *bp, PairTable t, DevCtl *c
 void launch_table_rehash(hipStream_t s, PairTable t, DevCtl *ctl);
 
 // best[0] = max over entries of pack_best(count, key)   (best must be zeroed)
-void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best);
+// hierarchical = one workgroup walking the block bounds (large tables); else a full scan
+void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best, bool hierarchical);
 
 // one merge pass over the stream, in place; new summaries of changed tiles go
 // to `side`, their bits are set in `chg` (launch_apply folds them into sums)

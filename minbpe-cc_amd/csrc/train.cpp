@@ -171,6 +171,7 @@ struct mbpe_ctx {
     int64_t opt_use_graph = 1;
     int64_t opt_time_kernels = 0;   // HIP events around every merge kernel (bench.py)
     int64_t opt_force_exchange = 0; // run the multi-rank path (edges, exchange) even with one rank
+    int64_t opt_hier_argmax = -1;   // -1 auto (by table size), 0 full scan, 1 hierarchical
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
 
     mbpe_stats stats = {};
@@ -196,6 +197,7 @@ void free_training(mbpe_ctx *c) {
     dfree(c->sums); dfree(c->side); dfree(c->chg);
     dfree(c->offsets);
     dfree(c->tab.hkey); dfree(c->tab.hidx); dfree(c->tab.ekey); dfree(c->tab.ecnt);
+    dfree(c->tab.bmax); dfree(c->tab.smax);
     dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->xb); dfree(c->xb0);
     dfree(c->d_left); dfree(c->d_right);
     c->LR = nullptr;
@@ -220,6 +222,11 @@ int alloc_table(mbpe_ctx *c, uint32_t ecap) {
     HIPCHK(hipMalloc(&c->tab.hidx, (size_t)c->hcap * 4));
     HIPCHK(hipMalloc(&c->tab.ekey, (size_t)ecap * 4));
     HIPCHK(hipMalloc(&c->tab.ecnt, (size_t)ecap * 4));
+    const size_t nb = ((size_t)ecap >> kBlockShift) + 2, ns = ((size_t)ecap >> (2 * kBlockShift)) + 2;
+    HIPCHK(hipMalloc(&c->tab.bmax, nb * 8));
+    HIPCHK(hipMalloc(&c->tab.smax, ns * 8));
+    HIPCHK(hipMemsetAsync(c->tab.bmax, 0, nb * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->tab.smax, 0, ns * 8, c->stream));
     launch_fill_u32(c->stream, c->tab.hkey, c->hcap, kEmptyKey);
     return MBPE_OK;
 }
@@ -234,7 +241,7 @@ uint64_t batch_headroom(const mbpe_ctx *c, uint32_t steps) {
 uint64_t table_cap_limit(const mbpe_ctx *c) {
     uint64_t v = c->vocab_size;
     uint64_t lim = v * v;                    // every possible pair
-    if (lim > 0xFFFFFFF0ull) lim = 0xFFFFFFF0ull;
+    if (lim > (1ull << 30)) lim = 1ull << 30;   // argmax hierarchy: 1024 super-blocks of 1024 x 1024 entries
     return std::max<uint64_t>(lim, 1024);
 }
 
@@ -249,9 +256,15 @@ int grow_table(mbpe_ctx *c, uint64_t want) {
     uint32_t n = c->h_ctl.n_entries;
     HIPCHK(hipMemcpyAsync(c->tab.ekey, old.ekey, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->tab.ecnt, old.ecnt, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+    // the block bounds refer to entry indices, which do not change
+    HIPCHK(hipMemcpyAsync(c->tab.bmax, old.bmax, (((size_t)old.ecap >> kBlockShift) + 2) * 8,
+                          hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->tab.smax, old.smax, (((size_t)old.ecap >> (2 * kBlockShift)) + 2) * 8,
+                          hipMemcpyDeviceToDevice, c->stream));
     launch_table_rehash(c->stream, c->tab, c->ctl);
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipFree(old.hkey); (void)hipFree(old.hidx); (void)hipFree(old.ekey); (void)hipFree(old.ecnt);
+    (void)hipFree(old.bmax); (void)hipFree(old.smax);
     return MBPE_OK;
 }
 
@@ -328,6 +341,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "use_graph") c->opt_use_graph = value;
     else if (n == "time_kernels") c->opt_time_kernels = value;
     else if (n == "force_exchange") c->opt_force_exchange = value;
+    else if (n == "hier_argmax") c->opt_hier_argmax = value;
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
 }
@@ -450,6 +464,12 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
 // enqueued back to back on the context's stream; in external mode the
 // library stops after *_local so that the caller can reduce the buffer.
 
+// large tables: walk the block bounds instead of scanning every entry ("hier_argmax": -1 auto, 0 never, 1 always)
+static inline bool use_hier(const mbpe_ctx *c) {
+    if (c->opt_hier_argmax >= 0) return c->opt_hier_argmax != 0;
+    return c->h_ctl.n_entries > (1u << 20);
+}
+
 static inline bool is_multi(const mbpe_ctx *c) { return c->n_ranks > 1 || c->opt_force_exchange; }
 
 static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
@@ -517,7 +537,7 @@ static int begin_finish(mbpe_ctx *c) {
         launch_compose_edges(c->stream, hdr, c->rank, c->n_ranks, c->d_left, c->d_right);
     }
     launch_table_init(c->stream, c->xb0, c->tab, c->ctl);
-    launch_argmax(c->stream, c->tab, c->ctl, c->best);
+    launch_argmax(c->stream, c->tab, c->ctl, c->best, use_hier(c));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     int rc = sync_ctl(c);
     if (rc != MBPE_OK) return rc;
@@ -552,7 +572,7 @@ static void step_finish(mbpe_ctx *c) {
     launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->LR, multi ? c->xb : nullptr, c->sums, c->side,
                  c->chg, c->n_tiles);
     if (multi) launch_compose_edges(c->stream, c->xb, c->rank, c->n_ranks, c->d_left, c->d_right);
-    launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1);
+    launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1, use_hier(c));
     c->k++;
 }
 

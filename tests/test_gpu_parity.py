@@ -225,3 +225,33 @@ def test_large_vocab_many_merges(tr):
     want_m, want_c = O.train(data, 4096)
     m, c, _ = tr.train_lexical(data, 4096)
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
+@pytest.mark.parametrize("hier", [0, 1])
+def test_argmax_variants_agree(tr, hier):
+    # full-scan argmax vs the hierarchical one (block upper bounds), incl. table growth
+    data = O.splitmix64_bytes(21, 1 << 17)
+    want_m, want_c = O.train(data, 3000)
+    tr.set_option("hier_argmax", hier)
+    tr.set_option("batch", 16)
+    try:
+        m, c, _ = tr.train_lexical(data, 3000)
+    finally:
+        tr.set_option("hier_argmax", -1)
+        tr.set_option("batch", 64)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
+def test_hier_argmax_text_zero_counts(tr):
+    tr.set_option("hier_argmax", 1)
+    try:
+        m, c, _ = tr.train_lexical(read_data("small.txt"), 275)
+        want = [[98, 99], [100, 101], [256, 257], [258, 258], [97, 259], [258, 10], [260, 261]] + [[97, 98]] * 12
+        assert m.tolist() == want
+        data = read_data("taylorswift.txt")
+        off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data)
+        want_m, want_c = O.train(data, 512, off)
+        m, c, _ = tr.train_lexical(data, 512, off)
+        assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+    finally:
+        tr.set_option("hier_argmax", -1)
