@@ -27,7 +27,8 @@ public:
     Splitter(const Splitter &) = delete;
     Splitter &operator=(const Splitter &) = delete;
 
-    int compile(const std::string &pattern, std::string *err);
+    int compile(const std::string &pattern, std::string *err);   // replaces any earlier pattern
+    void reset();
     // chunk c = [starts[c], ends[c]); empty pattern -> one chunk = whole text
     int split(const uint8_t *text, uint64_t n, std::vector<uint64_t> *starts,
               std::vector<uint64_t> *ends, std::string *err) const;

@@ -74,13 +74,18 @@ std::string pcre2_message(int code) {
 
 namespace mbpe_host {
 
-Splitter::~Splitter() {
+Splitter::~Splitter() { reset(); }
+
+void Splitter::reset() {
     if (match_data_) pcre2().match_data_free(match_data_);
     if (code_) pcre2().code_free(code_);
+    match_data_ = nullptr;
+    code_ = nullptr;
 }
 
 // Tokenizer(const string &pattern), Tokenizer.h:391-451.
 int Splitter::compile(const std::string &pattern, std::string *err) {
+    reset();
     pattern_ = pattern;
     if (pattern.empty()) return MBPE_OK;   // "basic": no split, Tokenizer.h:400
     Pcre2Api &p = pcre2();

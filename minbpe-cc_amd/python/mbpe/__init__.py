@@ -27,6 +27,11 @@ EXPORTS = [
     "mbpe_comm_exchange_buffer", "mbpe_comm_exchange_done", "mbpe_presplit",
     "mbpe_split_count", "mbpe_split_offsets", "mbpe_split_free", "mbpe_split_pattern",
 ]
+# include/mbpe_tokenizer.h
+TOK_EXPORTS = [
+    "mbpe_tok_create", "mbpe_tok_destroy", "mbpe_tok_set_special_tokens", "mbpe_tok_train", "mbpe_tok_set_merges",
+    "mbpe_tok_get_merges", "mbpe_tok_save", "mbpe_tok_load", "mbpe_tok_encode", "mbpe_tok_decode",
+]
 
 
 class Stats(ctypes.Structure):
@@ -89,6 +94,17 @@ def lib():
     L.mbpe_split_free.restype = None
     L.mbpe_split_pattern.argtypes = [ctypes.c_char_p]
     L.mbpe_split_pattern.restype = ctypes.c_char_p
+    L.mbpe_tok_create.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.mbpe_tok_destroy.argtypes = [vp]
+    L.mbpe_tok_destroy.restype = None
+    L.mbpe_tok_set_special_tokens.argtypes = [vp, ctypes.c_char_p, u64]
+    L.mbpe_tok_train.argtypes = [vp, vp, u64, u32, i32, i32, i32]
+    L.mbpe_tok_set_merges.argtypes = [vp, vp, u32]
+    L.mbpe_tok_get_merges.argtypes = [vp, vp, u32, vp]
+    L.mbpe_tok_save.argtypes = [vp, ctypes.c_char_p, i32]
+    L.mbpe_tok_load.argtypes = [vp, ctypes.c_char_p, i32]
+    L.mbpe_tok_encode.argtypes = [vp, vp, u64, i32, vp, u64, vp]
+    L.mbpe_tok_decode.argtypes = [vp, vp, u64, i32, vp, u64, vp]
     _lib = L
     return L
 
@@ -264,3 +280,67 @@ def comm_unique_id():
     buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
     _check(lib().mbpe_comm_unique_id(buf))
     return bytes(buf)
+
+
+class Tokenizer:
+    """Binding of include/mbpe_tokenizer.h: the host-side mirror of the reference Tokenizer."""
+
+    FIRST, LEXICAL = 0, 1
+
+    def __init__(self, pattern=""):
+        self._h = ctypes.c_void_p()
+        _check(lib().mbpe_tok_create(pattern.encode("utf-8"), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().mbpe_tok_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_special_tokens_from_file(self, text):
+        b = text if isinstance(text, bytes) else text.encode("utf-8")
+        _check(lib().mbpe_tok_set_special_tokens(self._h, b, len(b)))
+
+    def train(self, data, vocab_size, conflict_resolution=1, verbose=False, device=0):
+        text = _u8(data)
+        _check(lib().mbpe_tok_train(self._h, text.ctypes.data if len(text) else None, len(text), vocab_size,
+                                    conflict_resolution, int(verbose), device))
+
+    def set_merges(self, merges):
+        m = np.ascontiguousarray(merges, dtype=np.uint32).reshape(-1, 2)
+        _check(lib().mbpe_tok_set_merges(self._h, m.ctypes.data if len(m) else None, len(m)))
+
+    def merges(self):
+        n = ctypes.c_uint32()
+        _check(lib().mbpe_tok_get_merges(self._h, None, 0, ctypes.byref(n)))
+        m = np.zeros((max(n.value, 1), 2), dtype=np.uint32)
+        _check(lib().mbpe_tok_get_merges(self._h, m.ctypes.data, n.value, ctypes.byref(n)))
+        return m[:n.value]
+
+    def save(self, path, write_vocab=False):
+        _check(lib().mbpe_tok_save(self._h, os.fsencode(path), int(write_vocab)))
+
+    def load(self, path, verbose=False):
+        _check(lib().mbpe_tok_load(self._h, os.fsencode(path), int(verbose)))
+
+    def encode(self, data):
+        text = _u8(data)
+        n = ctypes.c_uint64()
+        out = np.zeros(max(len(text), 1), dtype=np.uint32)
+        _check(lib().mbpe_tok_encode(self._h, text.ctypes.data if len(text) else None, len(text), 0,
+                                     out.ctypes.data, len(out), ctypes.byref(n)))
+        return out[:n.value].copy()
+
+    def decode(self, tokens):
+        t = np.ascontiguousarray(tokens, dtype=np.uint32)
+        n = ctypes.c_uint64()
+        _check(lib().mbpe_tok_decode(self._h, t.ctypes.data if len(t) else None, len(t), 0, None, 0, ctypes.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.uint8)
+        _check(lib().mbpe_tok_decode(self._h, t.ctypes.data if len(t) else None, len(t), 0, out.ctypes.data,
+                                     len(out), ctypes.byref(n)))
+        return out[:n.value].tobytes()

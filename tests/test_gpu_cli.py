@@ -1,0 +1,63 @@
+"""GPU end-to-end tests through the drop-in command line (minbpe-cc_amd/minbpe-cc),
+mirroring the reference's endtoend-test.sh: train -> encode -> decode -> diff."""
+import os
+import subprocess
+
+import pytest
+
+import mbpe
+import oracle as O
+from conftest import GOLDEN, ROOT, read_data, read_golden
+
+pytestmark = pytest.mark.gpu
+
+CLI = os.path.join(ROOT, "minbpe-cc_amd", "minbpe-cc")
+DATA = os.path.join(GOLDEN, "data")
+
+
+def _run(*args):
+    r = subprocess.run([CLI] + [str(a) for a in args], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_e2e_basic_lexical(tmp_path):
+    # endtoend-test.sh:7-10
+    model, enc, dec = tmp_path / "basic-model", tmp_path / "enc", tmp_path / "dec"
+    out = _run("--train", "--input", os.path.join(DATA, "shakespeare.txt"), "--model-path", model,
+               "--vocab-size", 512, "--encoder", "basic", "--conflict-resolution", "lexical")
+    assert "Training using file" in out and "Writing model..." in out and "Complete." in out and "Execution time:" in out
+    assert model.read_bytes() == read_golden("shakespeare_basic_lexical_512.model")
+    _run("--encode", "--input", os.path.join(DATA, "sample.txt"), "--model-path", model, "--output", enc)
+    _run("--decode", "--input", enc, "--model-path", model, "--output", dec)
+    assert dec.read_bytes() == read_data("sample.txt")
+
+
+def test_e2e_gpt4_config5(tmp_path):
+    # BASELINE config 5: taylorswift, --encoder gpt4 (CLI default), vocab 512, round trip exact
+    model, enc, dec = tmp_path / "gpt4-model", tmp_path / "enc", tmp_path / "dec"
+    src = os.path.join(DATA, "taylorswift.txt")
+    out = _run("-t", "-i", src, "-m", model, "-c", "lexical", "-v", "-w")
+    assert "Split input text into 46196 chunks" in out
+    assert "merge 1/256: (101, 114) -> 256 (b'er') had 2359 occurrences" in out
+    assert "merge 256/256: (306, 388) -> 511" in out and "had 82 occurrences" in out
+    assert model.read_bytes() == read_golden("taylorswift_gpt4_lexical_512.model")
+    assert os.path.exists(str(model) + ".vocab")
+    out = _run("-e", "-i", src, "-m", model, "-o", enc)
+    assert "Writing 94201 encoded tokens" in out
+    _run("-d", "-i", enc, "-m", model, "-o", dec)
+    assert dec.read_bytes() == read_data("taylorswift.txt")
+
+
+def test_cli_first_mode_reports_unavailable(tmp_path):
+    r = subprocess.run([CLI, "-t", "-i", os.path.join(DATA, "small.txt"), "-m", str(tmp_path / "m"), "--encoder", "basic"],
+                       capture_output=True, text=True)    # default -c first
+    assert r.returncode == 255 and "lexical" in r.stderr
+
+
+def test_tokenizer_train_binding():
+    tok = mbpe.Tokenizer(O.GPT2_SPLIT_PATTERN)
+    tok.train(read_data("taylorswift.txt"), 512)
+    assert O.model_bytes(O.GPT2_SPLIT_PATTERN, tok.merges()) == read_golden("taylorswift_gpt2_lexical_512.model")
+    data = read_data("sample.txt")
+    assert tok.decode(tok.encode(data)) == data
