@@ -55,6 +55,20 @@ def splitmix64_device(seed, n, device, offset_bytes=0):
     return out, b
 
 
+def pmc_traffic(kernel, corpus_bytes, vocab, world):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), for the
+    workload they were taken on; None for any other configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            d = json.load(f)
+        w = d["workload"]
+        if w["corpus_bytes"] == corpus_bytes and w["vocab_size"] == vocab and w["n_gpus"] == world:
+            return d[kernel]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(seed, sample_bytes, merges, vocab):
     """The CPU oracle (a port of the reference algorithm: sequential pass per
     merge + incremental counts + ordered argmax) timed on one host core."""
@@ -201,7 +215,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic("k_merge", args.bytes, args.vocab, world),
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 PMC passes of this workload, early merges)",
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": avg_kernel_ms,
                 "launches": n_launch,
@@ -213,7 +228,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": scan_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic("k_pair_count_u8", args.bytes, args.vocab, world),
                 "algorithmic_bytes_per_launch": hi - lo,
                 "avg_launch_ms": scan_ms_best,
             },
