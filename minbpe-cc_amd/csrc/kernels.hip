@@ -70,6 +70,13 @@ __device__ __forceinline__ uint32_t wave_sum_le8(uint32_t v, unsigned long long 
 
 // ---- pair table device ops ------------------------------------------------
 
+// Count-delta vectors of up to kBatchMax simultaneous merges, x-major so that
+// the ids that exist (x < 256 + k) form a contiguous prefix:
+//   L_j[x] = LR[lr_idx(x, j, 0)],  R_j[y] = LR[lr_idx(y, j, 1)]
+__device__ __forceinline__ uint32_t lr_idx(uint32_t x, uint32_t j, uint32_t side) {
+    return ((x * kBatchMax + j) << 1) | side;
+}
+
 __device__ __forceinline__ uint32_t hash_key(uint32_t k) {
     k *= 0x9E3779B1u;
     k ^= k >> 15;
@@ -591,8 +598,8 @@ __global__ void k_table_rehash(PairTable t, DevCtl *ctl) {
 //   - count deltas (:239-280) are accumulated as
 //       L[x] += 1  for a match whose left neighbour is x   => (x,a)-1, (x,X)+1
 //       R[y] += 1  for a match whose right neighbour is y  => (b,y)-1, (X,y)+1
-//     (L[x] = LR[2x], R[y] = LR[2y+1]: one array, so that a multi-GPU run
-//      all-reduces a contiguous prefix)
+//     (L[x] = LR[lr_idx(x,0,0)], R[y] = LR[lr_idx(y,0,1)]: one array, so that a
+//      multi-GPU run all-reduces a contiguous prefix)
 //       adj  += 1  for two matches that touch ("abab")     => (b,a)-1, (X,X)+1
 //       m    += 1  per match                               => (a,b)-1
 //     which is the reference's sequential result: its transient (X,a)+1/-1
@@ -747,14 +754,14 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
             ++my_m;
             if (p1 != kHole && !(p1 & endbit)) {
                 if (prev_adjacent) ++my_adj;
-                else atomicAdd(&LR[2u * p1], 1u);
+                else atomicAdd(&LR[lr_idx(p1, 0, 0)], 1u);
             }
         } else if (bmatch) {
             nv = kHole;
             ++my_rm;
             if (!(self & endbit) && n1 != kHole) {
                 const bool next_adjacent = (n1 == a) && ((n2 & idmask) == b);
-                if (!next_adjacent) atomicAdd(&LR[2u * (n1 & idmask) + 1u], 1u);
+                if (!next_adjacent) atomicAdd(&LR[lr_idx(n1 & idmask, 0, 1)], 1u);
             }
         }
         p2 = p1; p1 = self;       // neighbours are the OLD tokens
@@ -780,7 +787,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
                                                          uint32_t *__restrict__ chg,
                                                          const unsigned long long *__restrict__ best_ptr,
                                                          uint32_t X, uint32_t *LR, DevCtl *ctl,
-                                                         const RankEdge *le, const RankEdge *re) {
+                                                         uint32_t *m_adj, const RankEdge *le,
+                                                         const RankEdge *re, int seq) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
@@ -788,6 +796,12 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     if (tile >= n_tiles) return;
 
+    if (seq) {      // inside a batch sequence: the merge index lives on the device
+        if (ctl->batch_n != 1) return;
+        const uint32_t k = ctl->k_done;
+        best_ptr += k;
+        X = 256u + k;
+    }
     const unsigned long long best = *best_ptr;
     if ((best >> 32) == 0) return;   // count 0 (or no pair at all): nothing can match
     const uint32_t key = ~(uint32_t)best;
@@ -855,8 +869,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
     }
     const uint32_t tm = wave_sum(wave_m), ta = wave_sum(wave_adj), tr = wave_sum(wave_rm);
     if (lane == 0) {
-        if (tm) atomicAdd(&ctl->m, tm);
-        if (ta) atomicAdd(&ctl->adj, ta);
+        if (tm) atomicAdd(&m_adj[0], tm);
+        if (ta) atomicAdd(&m_adj[1], ta);
         if (tr) atomicAdd(&ctl->rm, tr);
     }
 }
@@ -882,22 +896,430 @@ __device__ __forceinline__ void patch_sums(TileSum *sums, const TileSum *side, u
 }
 
 __global__ void k_patch_sums(const unsigned long long *__restrict__ best_ptr, TileSum *sums, const TileSum *side,
-                             uint32_t *chg, uint32_t n_chg_words) {
-    if ((*best_ptr >> 32) == 0) return;
+                             uint32_t *chg, uint32_t n_chg_words, DevCtl *ctl, int seq) {
+    if (seq) {
+        if (ctl->batch_n == 0) return;
+    } else if ((*best_ptr >> 32) == 0) {
+        return;
+    }
     patch_sums(sums, side, chg, n_chg_words, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__restrict__ best_ptr,
                         uint32_t X, uint32_t *LR, const uint32_t *gm_gadj, TileSum *sums,
-                        const TileSum *side, uint32_t *chg, uint32_t n_chg_words) {
+                        const TileSum *side, uint32_t *chg, uint32_t n_chg_words, int seq) {
+    if (seq) {
+        if (ctl->batch_n != 1) return;
+        const uint32_t k = ctl->k_done;
+        best_ptr += k;
+        X = 256u + k;
+    }
     const unsigned long long best = *best_ptr;
-    if ((best >> 32) == 0) return;   // count 0: the merge changed nothing (also covers "no pair")
-    const uint32_t key = ~(uint32_t)best;
-    const uint32_t a = key >> 16, b = key & 0xFFFFu;
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    patch_sums(sums, side, chg, n_chg_words, x, gridDim.x * blockDim.x);
-    if (x < X) {
-        const uint2 lr = reinterpret_cast<uint2 *>(LR)[x];
+    if ((best >> 32) != 0) {      // count 0: the merge changed nothing
+        const uint32_t key = ~(uint32_t)best;
+        const uint32_t a = key >> 16, b = key & 0xFFFFu;
+        patch_sums(sums, side, chg, n_chg_words, x, gridDim.x * blockDim.x);
+        for (uint32_t xx = x; xx < X; xx += gridDim.x * blockDim.x) {
+            uint2 *cell = reinterpret_cast<uint2 *>(LR + lr_idx(xx, 0, 0));
+            const uint2 lr = *cell;
+            if (lr.x) {
+                table_add(t, ctl, (xx << 16) | a, -(int32_t)lr.x, false);
+                table_add(t, ctl, (xx << 16) | X, (int32_t)lr.x, true);
+            }
+            if (lr.y) {
+                table_add(t, ctl, (b << 16) | xx, -(int32_t)lr.y, false);
+                table_add(t, ctl, (X << 16) | xx, (int32_t)lr.y, true);
+            }
+            if (lr.x | lr.y) *cell = make_uint2(0, 0);
+        }
+        if (x == 0) {
+            const uint32_t m = gm_gadj ? gm_gadj[0] : ctl->m;
+            const uint32_t adj = gm_gadj ? gm_gadj[1] : ctl->adj;
+            if (m) table_add(t, ctl, (a << 16) | b, -(int32_t)m, false);
+            if (adj) {
+                table_add(t, ctl, (b << 16) | a, -(int32_t)adj, false);
+                table_add(t, ctl, (X << 16) | X, (int32_t)adj, true);
+            }
+            // tokens removed from this shard = second tokens of matches it holds (with
+            // several ranks a match can straddle two shards, so this is not m)
+            const uint32_t rm = ctl->rm;
+            ctl->removed_total += rm;
+            ctl->n_live -= rm;
+            ctl->m = 0;
+            ctl->adj = 0;
+            ctl->rm = 0;
+        }
+    }
+}
+
+// ---- batched merges -----------------------------------------------------------------
+// Several merges per pass over the stream.  k_select_batch takes the next
+// candidates in argmax order as long as each one is INDEPENDENT of the ones
+// before it: for an earlier (a,b) and a later (c,d): d != a and c != b (then
+// merging (a,b) cannot change count(c,d), and occurrences of the two pairs
+// cannot overlap), no (t,t) pair and no zero count inside a multi-pair batch.
+// All pairs ranked before a candidate are in the batch, every other old pair
+// can only have lost count, so the candidate is the true next argmax unless a
+// pair created by the earlier merges of the batch ((x,X_i), (X_i,y), (X_p,X_i))
+// beats it.  That is checked exactly-or-conservatively AFTER the counting pass
+// (k_validate) and BEFORE anything is rewritten: the scan pass (k_scan_batch)
+// only counts deltas per pair and marks the tiles that hold matches; the
+// rewrite pass (k_rewrite_marked) then applies the validated prefix to the
+// marked tiles.  A batch of one pair (always valid) takes the fused single
+// pass k_merge instead.
+
+__global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevCtl *ctl, BatchState *bs,
+                                                               unsigned long long *best, uint32_t n_target,
+                                                               uint32_t max_batch) {
+    __shared__ Top2 sh[kHierThreads / kWave];
+    __shared__ uint32_t s_keys[kBatchMax];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k0 = ctl->k_done;
+    const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
+    const uint32_t n = ctl->n_entries < t.ecap ? ctl->n_entries : t.ecap;
+    __syncthreads();
+    if (tid == 0) { ctl->batch_n = 0; ctl->commit_n = 0; }
+    if (k0 >= k_limit || n == 0) return;
+    uint32_t limit = k_limit - k0;
+    if (limit > max_batch) limit = max_batch;
+    if (limit > (uint32_t)kBatchMax) limit = kBatchMax;
+    const uint32_t n_blocks = (n + kBlockSize - 1) >> kBlockShift;
+    const uint32_t n_super = (n_blocks + kBlockSize - 1) >> kBlockShift;
+    auto ld = [](const unsigned long long *p) {
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    uint32_t accepted = 0;
+    for (uint32_t k = 0; k < limit; ++k) {
+        // hierarchical argmax over the entries that are not yet in the batch
+        unsigned long long cand = 0;
+        uint32_t cand_idx = 0;
+        for (int round = 0; round < 1 << 20; ++round) {
+            const Top2 ts = block_top2(tid < n_super ? ld(&t.smax[tid]) : 0ull, tid, sh);
+            if (ts.v1 == 0ull) break;
+            const uint32_t S = ts.i1;
+            const uint32_t bidx = (S << kBlockShift) + tid;
+            const Top2 tb = block_top2(bidx < n_blocks ? ld(&t.bmax[bidx]) : 0ull, bidx, sh);
+            const uint32_t B = tb.i1;
+            const uint32_t e = (B << kBlockShift) + tid;
+            unsigned long long p = 0;
+            if (e < n) {
+                const int32_t c = t.ecnt[e];
+                const uint32_t key = t.ekey[e];
+                // a pair already in the batch will have count 0 once it is merged (a != b):
+                // it stays a (zero-count) candidate, SURVEY 8-S rule 4
+                bool excluded = false;
+                for (uint32_t i = 0; i < accepted; ++i) excluded |= s_keys[i] == key;
+                p = pack_best(excluded || c < 0 ? 0 : c, key);
+            }
+            const Top2 te = block_top2(p, e, sh);
+            const unsigned long long truth = te.v1;
+            const unsigned long long s_bound = truth > tb.v2 ? truth : tb.v2;
+            if (tid == 0) {
+                // (lowered below an accepted entry's count: k_validate restores the bounds of
+                //  accepted pairs that end up not being merged)
+                __hip_atomic_store(&t.bmax[B], truth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&t.smax[S], s_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (truth >= tb.v2 && truth >= ts.v2) { cand = truth; cand_idx = te.i1; break; }
+            __syncthreads();
+        }
+        if (cand == 0ull) break;
+        const uint32_t count = (uint32_t)(cand >> 32), key = ~(uint32_t)cand;
+        const uint32_t a = key >> 16, b = key & 0xFFFFu;
+        const bool single = count == 0 || a == b;
+        if (k > 0) {
+            bool conflict = single;
+            for (uint32_t i = 0; i < accepted; ++i) {
+                const uint32_t ai = s_keys[i] >> 16, bi = s_keys[i] & 0xFFFFu;
+                conflict |= (b == ai) || (a == bi);
+            }
+            if (conflict) break;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_keys[accepted] = key;
+            bs->key[accepted] = key;
+            bs->eidx[accepted] = cand_idx;
+            bs->packed[accepted] = cand;
+            bs->max_l[accepted] = 0;
+            bs->max_r[accepted] = 0;
+            best[k0 + accepted] = cand;
+        }
+        ++accepted;
+        __syncthreads();
+        if (single) break;
+    }
+    if (tid == 0) {
+        ctl->batch_n = accepted;
+        ctl->commit_n = accepted;      // k_validate lowers it for multi-pair batches
+        if (accepted) ctl->n_batches += 1;
+    }
+}
+
+// exact neighbours of every slot, two deep on both sides (shared by the scan
+// and rewrite passes of a batch)
+struct Neigh {
+    uint32_t p1_in, p2_in;      // live tokens before this lane's first slot
+    uint32_t n1v[8], n2v[8];    // next / second-next live token of every slot
+};
+
+__device__ __forceinline__ Neigh tile_neighbours(const uint32_t s[8], const Halo &h) {
+    const uint32_t lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    uint32_t cnt = 0, f1 = kSent, f2 = kSent, l1 = kSent, l2 = kSent;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (s[j] != kHole) {
+            if (cnt == 0) f1 = s[j]; else if (cnt == 1) f2 = s[j];
+            l2 = l1; l1 = s[j];
+            ++cnt;
+        }
+    }
+    const unsigned long long m_live = __ballot(cnt > 0);
+    Neigh nb;
+    {
+        const unsigned long long lo = m_live & lt_mask;
+        const uint32_t src1 = lo ? 63u - (uint32_t)__builtin_clzll(lo) : lane;
+        const uint32_t sl1 = __shfl(l1, src1, kWave), sl2 = __shfl(l2, src1, kWave);
+        const unsigned long long lo2 = lo & ~(1ull << src1);
+        const uint32_t src2 = lo2 ? 63u - (uint32_t)__builtin_clzll(lo2) : lane;
+        const uint32_t tl1 = __shfl(l1, src2, kWave);
+        nb.p1_in = lo ? sl1 : h.p1;
+        nb.p2_in = lo ? (sl2 != kSent ? sl2 : (lo2 ? tl1 : h.p1)) : h.p2;
+    }
+    uint32_t n1_in, n2_in;
+    {
+        const unsigned long long hi = m_live & gt_mask;
+        const uint32_t src1 = hi ? (uint32_t)__builtin_ctzll(hi) : lane;
+        const uint32_t sf1 = __shfl(f1, src1, kWave), sf2 = __shfl(f2, src1, kWave);
+        const unsigned long long hi2 = hi & ~(1ull << src1);
+        const uint32_t src2 = hi2 ? (uint32_t)__builtin_ctzll(hi2) : lane;
+        const uint32_t tf1 = __shfl(f1, src2, kWave);
+        n1_in = hi ? sf1 : h.n1;
+        n2_in = hi ? (sf2 != kSent ? sf2 : (hi2 ? tf1 : h.n1)) : h.n2;
+    }
+    uint32_t x1 = n1_in, x2 = n2_in;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        nb.n1v[j] = x1;
+        nb.n2v[j] = x2;
+        if (s[j] != kHole) { x2 = x1; x1 = s[j]; }
+    }
+    return nb;
+}
+
+// index of the batch pair with this key, or -1
+__device__ __forceinline__ int find_pair(const uint32_t *keys, uint32_t n_keys, uint32_t key) {
+    int r = -1;
+    for (uint32_t j = 0; j < n_keys; ++j) r = keys[j] == key ? (int)j : r;
+    return r;
+}
+
+// The counting half of a multi-pair merge on one tile: deltas per pair and the
+// tile's mark.  Nothing is rewritten.
+template <bool CHUNKED>
+__device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, const uint32_t s[8], const Halo h,
+                                               const uint32_t *keys, uint32_t n_keys, uint32_t *hdr_m,
+                                               uint32_t *hdr_adj, uint32_t *LR) {
+    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    const Neigh nb = tile_neighbours(s, h);
+    bool any = false;
+    uint32_t p1 = nb.p1_in, p2 = nb.p2_in;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t self = s[j];
+        if (self == kHole) continue;
+        const uint32_t n1 = nb.n1v[j], n2 = nb.n2v[j];
+        const int ja = n1 == kHole ? -1 : find_pair(keys, n_keys, self | ((n1 & idmask) << 16));
+        if (ja >= 0) {                       // first token of a match of pair ja
+            any = true;
+            atomicAdd(&hdr_m[ja], 1u);
+            if (p1 != kHole && !(p1 & endbit)) {
+                const int jp = p2 == kHole ? -1 : find_pair(keys, n_keys, p2 | (p1 << 16));
+                if (jp >= 0) atomicAdd(&hdr_adj[jp * kBatchMax + ja], 1u);     // two matches touch
+                else atomicAdd(&LR[lr_idx(p1, (uint32_t)ja, 0)], 1u);
+            }
+        } else {
+            const int jb = p1 == kHole ? -1 : find_pair(keys, n_keys, p1 | ((self & idmask) << 16));
+            if (jb >= 0) {                   // second token of a match of pair jb
+                any = true;
+                if (!(self & endbit) && n1 != kHole) {
+                    const int jn = n2 == kHole ? -1 : find_pair(keys, n_keys, n1 | ((n2 & idmask) << 16));
+                    if (jn < 0) atomicAdd(&LR[lr_idx(n1 & idmask, (uint32_t)jb, 1)], 1u);
+                }
+            }
+        }
+        p2 = p1; p1 = self;
+    }
+    if (__ballot(any) != 0ull && lane_id() == 0) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
+}
+
+template <bool CHUNKED>
+__global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__restrict__ tok,
+                                                              const TileSum *__restrict__ sin, uint32_t n_tiles,
+                                                              uint32_t *__restrict__ chg, const BatchState *bs,
+                                                              uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
+                                                              const DevCtl *ctl, const RankEdge *le,
+                                                              const RankEdge *re) {
+    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    const uint32_t lane = lane_id();
+    const uint32_t waves_per_block = kMergeThreads / kWave;
+    const uint32_t n_waves = gridDim.x * waves_per_block;
+    uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
+    if (tile >= n_tiles) return;
+    const uint32_t n_keys = ctl->batch_n;
+    if (n_keys < 2) return;
+    // pair keys, also as (first | second << 16): the layout of a slot and its successor
+    __shared__ uint32_t s_keys[kBatchMax], s_kk[kBatchMax];
+    if (threadIdx.x < kBatchMax) {
+        const uint32_t key = threadIdx.x < n_keys ? bs->key[threadIdx.x] : 0xFFFFFFFFu;
+        s_keys[threadIdx.x] = key;
+        s_kk[threadIdx.x] = key == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((key >> 16) | (key << 16));
+    }
+    __syncthreads();
+
+    const uint32_t last_tile = n_tiles - 1;
+    auto clamp_tile = [&](uint64_t t) { return (uint32_t)(t < n_tiles ? t : last_tile); };
+    const __amdgpu_buffer_rsrc_t sums_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
+    TileIn t0 = tile_issue(tok, sums_rsrc, tile);
+    TileIn t1 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + n_waves));
+    TileIn t2 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 2ull * n_waves));
+    bool v1 = (uint64_t)tile + n_waves < n_tiles, v2 = (uint64_t)tile + 2ull * n_waves < n_tiles;
+    const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    for (;;) {
+        const bool v3 = (uint64_t)tile + 3ull * n_waves < n_tiles;
+        TileIn t3 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 3ull * n_waves));
+
+        const uint32_t me_nlive = rlane(t0.sm.z, 1) & 0xFFFFu;
+        if (me_nlive != 0) {
+            uint32_t s[8];
+            unpack8(t0.q, s);
+            Halo h;
+            const uint32_t pw1 = rlane(t0.sm.y, 0), pw2 = rlane(t0.sm.z, 0);
+            const uint32_t nw0 = rlane(t0.sm.x, 2), nw2 = rlane(t0.sm.z, 2);
+            const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
+            if (fast) {
+                h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
+                h.n1 = nw0 & 0xFFFFu; h.n2 = nw0 >> 16;
+            } else {
+                h = halo_slow(sin, n_tiles, tile, le, re);
+            }
+            // first live token of the lanes after this one (exact), then the candidate
+            // test: some slot and its next live token form one of the batch pairs
+            uint32_t lf = kHole;
+#pragma unroll
+            for (int j = 7; j >= 0; --j) lf = s[j] != kHole ? s[j] : lf;
+            const unsigned long long m_live = __ballot(lf != kHole);
+            const unsigned long long hi = m_live & gt_mask;
+            const uint32_t nf = __shfl(lf, hi ? (uint32_t)__builtin_ctzll(hi) : lane, kWave);
+            uint32_t c = hi ? nf : h.n1;
+            uint32_t acc = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 7; j >= 0; --j) {
+                const uint32_t key = s[j] | ((CHUNKED ? (c & idmask) : c) << 16);
+                if (n_keys <= 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const uint32_t x = key ^ s_kk[q]; acc = x < acc ? x : acc; }
+                } else if (n_keys <= 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const uint32_t x = key ^ s_kk[q]; acc = x < acc ? x : acc; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < kBatchMax; ++q) { const uint32_t x = key ^ s_kk[q]; acc = x < acc ? x : acc; }
+                }
+                c = s[j] != kHole ? s[j] : c;
+            }
+            bool work = __ballot(acc == 0u) != 0ull;
+            if (!work && h.p1 != kHole) {      // a match whose first token is the previous tile's last
+                for (uint32_t q = 0; q < n_keys; ++q) work |= (s_keys[q] >> 16) == h.p1;
+            }
+            if (work) scan_tile_full<CHUNKED>(chg, tile, s, h, s_kk, n_keys, hdr_m, hdr_adj, LR);
+        }
+        if (!v1) break;
+        tile += n_waves;
+        t0 = t1; t1 = t2; t2 = t3;
+        v1 = v2; v2 = v3;
+    }
+}
+
+// largest entry of every L_j / R_j (after the all-reduce in a multi-GPU run)
+__global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, const DevCtl *ctl) {
+    const uint32_t n_keys = ctl->batch_n;
+    if (n_keys < 2) return;
+    const uint32_t X = 256u + ctl->k_done;
+    const uint64_t total = (uint64_t)X * kBatchMax;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t j = (uint32_t)(i % kBatchMax);
+        if (j >= n_keys) continue;
+        const uint2 lr = reinterpret_cast<const uint2 *>(LR)[i];
+        if (lr.x) atomicMax(&bs->max_l[j], lr.x);
+        if (lr.y) atomicMax(&bs->max_r[j], lr.y);
+    }
+}
+
+// How many pairs of the batch the sequential algorithm would really have
+// chosen in this order: pair j stays iff its count beats every pair the
+// merges before it can have created.  Then the deltas of the surviving prefix
+// are made exact for "only the prefix is merged", and the argmax bounds of the
+// dropped pairs are restored.
+__global__ void k_validate(PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
+                           uint32_t *LR) {
+    if (blockIdx.x || threadIdx.x) return;
+    const uint32_t n = ctl->batch_n;
+    if (n < 2) return;
+    uint32_t commit = n;
+    uint32_t max_adj = 0;
+    for (uint32_t i = 0; i < n * (uint32_t)kBatchMax; ++i) {
+        const uint32_t v = hdr_adj[(i / kBatchMax) * kBatchMax + (i % kBatchMax)];
+        max_adj = v > max_adj ? v : max_adj;
+    }
+    unsigned long long bound = 0;     // upper bound of the count of any pair created so far
+    for (uint32_t j = 1; j < n; ++j) {
+        const unsigned long long l = (unsigned long long)bs->max_l[j - 1] + max_adj;
+        const unsigned long long r = (unsigned long long)bs->max_r[j - 1] + max_adj;
+        const unsigned long long u = l > r ? l : r;
+        bound = u > bound ? u : bound;
+        if ((bs->packed[j] >> 32) <= bound) { commit = j; break; }   // ties go to the safe side
+    }
+    // a match of a kept pair that touches a match of a dropped pair keeps its plain neighbour
+    for (uint32_t j = 0; j < commit; ++j)
+        for (uint32_t p = commit; p < n; ++p) {
+            const uint32_t ap = bs->key[p] >> 16, bp = bs->key[p] & 0xFFFFu;
+            const uint32_t in = hdr_adj[p * kBatchMax + j], out = hdr_adj[j * kBatchMax + p];
+            if (in) { LR[lr_idx(bp, j, 0)] += in; hdr_adj[p * kBatchMax + j] = 0; }
+            if (out) { LR[lr_idx(ap, j, 1)] += out; hdr_adj[j * kBatchMax + p] = 0; }
+        }
+    for (uint32_t p = commit; p < n; ++p) {
+        const uint32_t e = bs->eidx[p];
+        atomicMax(&t.bmax[e >> kBlockShift], bs->packed[p]);
+        atomicMax(&t.smax[e >> (2 * kBlockShift)], bs->packed[p]);
+    }
+    ctl->commit_n = commit;
+}
+
+// table updates of the surviving prefix; clears every delta of the batch
+__global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
+                              uint32_t *LR) {
+    const uint32_t n = ctl->batch_n;
+    if (n < 2) return;
+    const uint32_t commit = ctl->commit_n;
+    const uint32_t k0 = ctl->k_done;
+    const uint32_t X0 = 256u + k0;
+    const uint64_t total = (uint64_t)X0 * kBatchMax;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t i = gid; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t j = (uint32_t)(i % kBatchMax), x = (uint32_t)(i / kBatchMax);
+        if (j >= n) continue;
+        uint2 *cell = reinterpret_cast<uint2 *>(LR) + i;
+        const uint2 lr = *cell;
+        if (!(lr.x | lr.y)) continue;
+        *cell = make_uint2(0, 0);
+        if (j >= commit) continue;
+        const uint32_t a = bs->key[j] >> 16, b = bs->key[j] & 0xFFFFu, X = X0 + j;
         if (lr.x) {
             table_add(t, ctl, (x << 16) | a, -(int32_t)lr.x, false);
             table_add(t, ctl, (x << 16) | X, (int32_t)lr.x, true);
@@ -906,26 +1328,106 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
             table_add(t, ctl, (b << 16) | x, -(int32_t)lr.y, false);
             table_add(t, ctl, (X << 16) | x, (int32_t)lr.y, true);
         }
-        if (lr.x | lr.y) reinterpret_cast<uint2 *>(LR)[x] = make_uint2(0, 0);
     }
-    if (x == 0) {
-        const uint32_t m_local = ctl->m;
-        const uint32_t m = gm_gadj ? gm_gadj[0] : m_local;
-        const uint32_t adj = gm_gadj ? gm_gadj[1] : ctl->adj;
-        if (m) table_add(t, ctl, (a << 16) | b, -(int32_t)m, false);
+    if (gid < (uint64_t)kBatchMax * kBatchMax) {
+        const uint32_t p = (uint32_t)gid / kBatchMax, j = (uint32_t)gid % kBatchMax;
+        const uint32_t adj = hdr_adj[gid];
         if (adj) {
-            table_add(t, ctl, (b << 16) | a, -(int32_t)adj, false);
-            table_add(t, ctl, (X << 16) | X, (int32_t)adj, true);
+            hdr_adj[gid] = 0;
+            if (p < commit && j < commit) {     // match of p directly followed by a match of j
+                const uint32_t bp = bs->key[p] & 0xFFFFu, aj = bs->key[j] >> 16;
+                table_add(t, ctl, (bp << 16) | aj, -(int32_t)adj, false);
+                table_add(t, ctl, ((X0 + p) << 16) | (X0 + j), (int32_t)adj, true);
+            }
         }
-        // tokens removed from this shard = second tokens of matches it holds (with
-        // several ranks a match can straddle two shards, so this is not m)
+    }
+    if (gid < (uint64_t)kBatchMax) {
+        const uint32_t m = hdr_m[gid];
+        if (m) {
+            hdr_m[gid] = 0;
+            if (gid < commit) table_add(t, ctl, bs->key[gid], -(int32_t)m, false);
+        }
+    }
+}
+
+// The rewriting half: tiles marked by the scan pass, pairs of the validated prefix.
+template <bool CHUNKED>
+__global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *__restrict__ tok,
+                                                                  const TileSum *__restrict__ sin,
+                                                                  TileSum *__restrict__ sout, uint32_t n_tiles,
+                                                                  uint32_t *__restrict__ chg, const BatchState *bs,
+                                                                  DevCtl *ctl, const RankEdge *le,
+                                                                  const RankEdge *re) {
+    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    if (ctl->batch_n < 2) return;
+    const uint32_t n_keys = ctl->commit_n;
+    const uint32_t X0 = 256u + ctl->k_done;
+    __shared__ uint32_t s_kk[kBatchMax];
+    if (threadIdx.x < kBatchMax) {
+        const uint32_t key = bs->key[threadIdx.x];
+        s_kk[threadIdx.x] = threadIdx.x < n_keys ? ((key >> 16) | (key << 16)) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const uint32_t lane = lane_id();
+    const uint32_t waves_per_block = kMergeThreads / kWave;
+    const uint32_t n_waves = gridDim.x * waves_per_block;
+    const uint32_t n_words = (n_tiles + 31u) / 32u;
+    uint32_t wave_rm = 0;
+    for (uint32_t w = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave); w < n_words; w += n_waves) {
+        uint32_t bits = chg[w];
+        while (bits) {
+            const uint32_t tile = w * 32u + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            const uint4 q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kWave + lane];
+            uint32_t s[8];
+            unpack8(q, s);
+            const Halo h = halo_slow(sin, n_tiles, tile, le, re);
+            const Neigh nb = tile_neighbours(s, h);
+            bool changed = false;
+            uint32_t p1 = nb.p1_in, my_rm = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t self = s[j];
+                if (self == kHole) continue;
+                const uint32_t n1 = nb.n1v[j];
+                const int ja = n1 == kHole ? -1 : find_pair(s_kk, n_keys, self | ((n1 & idmask) << 16));
+                if (ja >= 0) {
+                    s[j] = (X0 + (uint32_t)ja) | (n1 & endbit);
+                    changed = true;
+                } else if (p1 != kHole && find_pair(s_kk, n_keys, p1 | ((self & idmask) << 16)) >= 0) {
+                    s[j] = kHole;
+                    changed = true;
+                    ++my_rm;
+                }
+                p1 = self;
+            }
+            if (changed) reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
+            wave_rm += my_rm;
+            if (__ballot(changed) != 0ull) {
+                const uint4 ns = wave_summary(s);
+                if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
+            } else if (lane == 0) {
+                atomicAnd(&chg[w], ~(1u << (tile & 31u)));    // marked for a pair that was dropped
+            }
+        }
+    }
+    const uint32_t tr = wave_sum(wave_rm);
+    if (lane == 0 && tr) atomicAdd(&ctl->rm, tr);
+}
+
+// last kernel of a sequence: advance the merge counter
+__global__ void k_seq_finish(DevCtl *ctl) {
+    if (blockIdx.x || threadIdx.x) return;
+    if (ctl->batch_n >= 2) {       // (a single-pair batch was accounted by k_apply)
         const uint32_t rm = ctl->rm;
         ctl->removed_total += rm;
         ctl->n_live -= rm;
-        ctl->m = 0;
-        ctl->adj = 0;
         ctl->rm = 0;
     }
+    ctl->k_done += ctl->commit_n;
+    ctl->batch_n = 0;
+    ctl->commit_n = 0;
 }
 
 // ---- compaction ---------------------------------------------------------------------
@@ -1152,48 +1654,98 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 
 void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sin, TileSum *sout, uint32_t n_tiles,
                   uint32_t *chg, const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *LR,
-                  DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus) {
+                  DevCtl *ctl, uint32_t *m_adj, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus,
+                  int seq) {
     if (!n_tiles) return;
     const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_MERGE_DIAG") ? atoi(getenv("MBPE_MERGE_DIAG")) : 0;
     if (diag == 1 && !endbit) {
         hipLaunchKernelGGL((k_merge<false, 1>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           left_edge, right_edge);
+                           m_adj, left_edge, right_edge, seq);
         return;
     }
     if (diag == 2 && !endbit) {
         hipLaunchKernelGGL((k_merge<false, 2>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           left_edge, right_edge);
+                           m_adj, left_edge, right_edge, seq);
         return;
     }
 #endif
     if (endbit)
         hipLaunchKernelGGL((k_merge<true, 0>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           left_edge, right_edge);
+                           m_adj, left_edge, right_edge, seq);
     else
         hipLaunchKernelGGL((k_merge<false, 0>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           left_edge, right_edge);
+                           m_adj, left_edge, right_edge, seq);
 }
 
 void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best, uint32_t new_id,
                   uint32_t *LR, const uint32_t *gm_gadj, TileSum *sums, const TileSum *side,
-                  uint32_t *chg, uint32_t n_tiles) {
+                  uint32_t *chg, uint32_t n_tiles, int seq) {
+    // new_id: the id of the new token, or (seq != 0) an upper bound of it
     const uint32_t n_words = (n_tiles + 31u) / 32u;
     uint32_t blocks = (new_id + 255) / 256;
     const uint32_t want = (n_words + 255) / 256;
     if (want > blocks) blocks = want < 2048 ? want : 2048;
     hipLaunchKernelGGL(k_apply, dim3(blocks), dim3(256), 0, s, t, ctl, best, new_id, LR, gm_gadj, sums, side, chg,
-                       n_words);
+                       n_words, seq);
 }
 
 void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *sums, const TileSum *side,
-                       uint32_t *chg, uint32_t n_tiles) {
+                       uint32_t *chg, uint32_t n_tiles, DevCtl *ctl, int seq) {
     const uint32_t n_words = (n_tiles + 31u) / 32u;
     uint32_t blocks = (n_words + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_patch_sums, dim3(blocks), dim3(256), 0, s, best, sums, side, chg, n_words);
+    hipLaunchKernelGGL(k_patch_sums, dim3(blocks), dim3(256), 0, s, best, sums, side, chg, n_words, ctl, seq);
+}
+
+void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, unsigned long long *best,
+                         uint32_t n_target, uint32_t max_batch) {
+    hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch);
+}
+
+void launch_scan_batch(hipStream_t s, const uint16_t *tok, const TileSum *sums, uint32_t n_tiles, uint32_t *chg,
+                       const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR, const DevCtl *ctl,
+                       const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus) {
+    if (!n_tiles) return;
+    const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
+    if (endbit)
+        hipLaunchKernelGGL(k_scan_batch<true>, grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge);
+    else
+        hipLaunchKernelGGL(k_scan_batch<false>, grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge);
+}
+
+void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
+                         uint32_t *LR, uint32_t id_upper) {
+    // id_upper: upper bound of the ids that exist (the kernels read the exact value from ctl)
+    const uint64_t cells = (uint64_t)id_upper * kBatchMax;
+    uint32_t blocks = (uint32_t)((cells + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 2) blocks = 2;
+    hipLaunchKernelGGL(k_delta_max, dim3(blocks), dim3(256), 0, s, LR, bs, ctl);
+    hipLaunchKernelGGL(k_validate, dim3(1), dim3(64), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
+    hipLaunchKernelGGL(k_apply_batch, dim3(blocks), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
+}
+
+void launch_rewrite_marked(hipStream_t s, uint16_t *tok, const TileSum *sums, TileSum *side, uint32_t n_tiles,
+                           uint32_t *chg, const BatchState *bs, DevCtl *ctl, const RankEdge *left_edge,
+                           const RankEdge *right_edge, uint32_t endbit, int n_cus) {
+    if (!n_tiles) return;
+    const uint32_t n_words = (n_tiles + 31u) / 32u;
+    const dim3 grid(tile_grid(n_words, n_cus)), block(kMergeThreads);
+    if (endbit)
+        hipLaunchKernelGGL(k_rewrite_marked<true>, grid, block, 0, s, tok, sums, side, n_tiles, chg, bs, ctl, left_edge,
+                           right_edge);
+    else
+        hipLaunchKernelGGL(k_rewrite_marked<false>, grid, block, 0, s, tok, sums, side, n_tiles, chg, bs, ctl, left_edge,
+                           right_edge);
+}
+
+void launch_seq_finish(hipStream_t s, DevCtl *ctl) {
+    hipLaunchKernelGGL(k_seq_finish, dim3(1), dim3(64), 0, s, ctl);
 }
 
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles, unsigned long long *offsets,

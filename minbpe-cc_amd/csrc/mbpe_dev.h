@@ -74,8 +74,28 @@ struct DevCtl {
     unsigned long long n_live;         // live tokens in this rank's shard
     unsigned long long scan_total;     // output of the tile scan (compaction)
     uint32_t rm;             // tokens removed from THIS rank's shard by the current merge
-    uint32_t pad[5];
+    // ---- batched merges: the merge counter lives on the device ----
+    uint32_t k_done;         // merges committed so far
+    uint32_t k_limit;        // do not go beyond this many merges (host sets it per call)
+    uint32_t batch_n;        // candidates selected for the current batch (0: nothing to do)
+    uint32_t commit_n;       // how many of them survive validation
+    uint32_t n_batches;      // batches that did work (statistics)
 };
+
+// A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
+// stream (see k_select_batch).  Per batch scratch, device memory:
+constexpr int kBatchMax = 16;
+struct BatchState {
+    uint32_t key[kBatchMax];      // (first << 16) | second
+    uint32_t eidx[kBatchMax];     // entry index in the pair table
+    unsigned long long packed[kBatchMax];   // (count << 32) | ~key, as in best[]
+    uint32_t max_l[kBatchMax];    // max_x L_j[x]  (k_delta_max)
+    uint32_t max_r[kBatchMax];    // max_y R_j[y]
+};
+
+// exchange buffer (u32 words): [single-merge header: m, adj, RankEdge x n_ranks]
+//   [batch header: m_j (kBatchMax), ADJ[i][j] (kBatchMax^2)] [LR_j blocks: 2*stride words each]
+inline uint32_t batch_header_words() { return (uint32_t)(kBatchMax + kBatchMax * kBatchMax); }
 
 constexpr uint32_t kErrTableFull   = 1u;
 constexpr uint32_t kErrNegCount    = 2u;
@@ -121,17 +141,33 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 // to `side`, their bits are set in `chg` (launch_apply folds them into sums)
 void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sums, TileSum *side,
                   uint32_t n_tiles, uint32_t *chg, const unsigned long long *best, uint32_t new_id,
-                  uint32_t endbit, uint32_t *LR, DevCtl *ctl,
-                  const RankEdge *left_edge, const RankEdge *right_edge, int n_cus);
+                  uint32_t endbit, uint32_t *LR, DevCtl *ctl, uint32_t *m_adj /* [m, adj] accumulators */,
+                  const RankEdge *left_edge, const RankEdge *right_edge, int n_cus, int seq);
+// seq != 0: the kernel runs inside a batch sequence: it reads the merge index
+// from ctl->k_done and returns at once unless the selected batch has one pair
 
 // fold the merge's count deltas (L, R, m, adj) into the pair table
 // (L[x] = LR[2x], R[y] = LR[2y+1])
 void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best,
                   uint32_t new_id, uint32_t *LR, const uint32_t *gm_gadj,
-                  TileSum *sums, const TileSum *side, uint32_t *chg, uint32_t n_tiles);
+                  TileSum *sums, const TileSum *side, uint32_t *chg, uint32_t n_tiles, int seq);
 // only the summary fold of launch_apply (multi-GPU: it must precede the rank edge)
 void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *sums, const TileSum *side,
-                       uint32_t *chg, uint32_t n_tiles);
+                       uint32_t *chg, uint32_t n_tiles, DevCtl *ctl, int seq);
+
+// ---- batched merges (see kernels.hip "batched merges") ----
+void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, unsigned long long *best,
+                         uint32_t n_target, uint32_t max_batch);
+void launch_scan_batch(hipStream_t s, const uint16_t *tok, const TileSum *sums, uint32_t n_tiles, uint32_t *chg,
+                       const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR, const DevCtl *ctl,
+                       const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus);
+// k_delta_max + k_validate + k_apply_batch
+void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
+                         uint32_t *LR, uint32_t id_upper);
+void launch_rewrite_marked(hipStream_t s, uint16_t *tok, const TileSum *sums, TileSum *side, uint32_t n_tiles,
+                           uint32_t *chg, const BatchState *bs, DevCtl *ctl, const RankEdge *left_edge,
+                           const RankEdge *right_edge, uint32_t endbit, int n_cus);
+void launch_seq_finish(hipStream_t s, DevCtl *ctl);
 
 // compaction: exclusive scan of n_live over tiles, then scatter
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles,

@@ -144,8 +144,11 @@ struct mbpe_ctx {
     unsigned long long *best = nullptr;   // [n_target + 1]
     // exchange buffer of one merge: [header: m, adj, RankEdge x n_ranks][LR: L[x], R[x] interleaved]
     uint32_t *xb = nullptr;
-    uint32_t hdr_words = 0;
-    uint32_t *LR = nullptr;               // xb + hdr_words
+    uint32_t hdr_words = 0;               // single-merge header: m, adj, RankEdge x n_ranks
+    uint32_t hdrb_words = 0;              // batch header: m_j, ADJ
+    uint32_t *hdr_m = nullptr, *hdr_adj = nullptr;   // inside xb
+    uint32_t *LR = nullptr;               // xb + hdr_words + hdrb_words
+    BatchState *bs = nullptr;
     uint32_t *xb0 = nullptr;              // begin: [bp 65,536][header]
     RankEdge *d_left = nullptr, *d_right = nullptr;   // composed neighbours (multi-GPU)
 
@@ -163,7 +166,7 @@ struct mbpe_ctx {
     bool comm_external = false;           // the caller performs the all-reduce
     void *nccl_comm = nullptr;
     int pending = 0;                      // external mode: 0 none, 1 begin, 2 step
-    uint32_t pending_steps = 0, pending_done = 0;
+    uint32_t pending_target = 0;          // external mode: merge count the pending call runs up to
 
     // options
     int64_t opt_compact_den = 8;
@@ -172,6 +175,9 @@ struct mbpe_ctx {
     int64_t opt_time_kernels = 0;   // HIP events around every merge kernel (bench.py)
     int64_t opt_force_exchange = 0; // run the multi-rank path (edges, exchange) even with one rank
     int64_t opt_hier_argmax = -1;   // -1 auto (by table size), 0 full scan, 1 hierarchical
+    int64_t opt_multi_merge = 1;    // 1: several independent merges per stream pass (batch sequences)
+    int64_t opt_max_batch = kBatchMax;
+    uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
 
     mbpe_stats stats = {};
@@ -199,7 +205,7 @@ void free_training(mbpe_ctx *c) {
     dfree(c->tab.hkey); dfree(c->tab.hidx); dfree(c->tab.ekey); dfree(c->tab.ecnt);
     dfree(c->tab.bmax); dfree(c->tab.smax);
     dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->xb); dfree(c->xb0);
-    dfree(c->d_left); dfree(c->d_right);
+    dfree(c->d_left); dfree(c->d_right); dfree(c->bs);
     c->LR = nullptr;
     c->pending = 0;
     c->begun = false;
@@ -342,6 +348,8 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "time_kernels") c->opt_time_kernels = value;
     else if (n == "force_exchange") c->opt_force_exchange = value;
     else if (n == "hier_argmax") c->opt_hier_argmax = value;
+    else if (n == "multi_merge") c->opt_multi_merge = value;
+    else if (n == "max_batch") c->opt_max_batch = std::min<int64_t>(std::max<int64_t>(1, value), kBatchMax);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
 }
@@ -486,19 +494,25 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     if (c->n_slots / kTile > 0x0FFFFFF0ull) { mbpe_host::set_last_error("corpus shard too large"); return MBPE_ERR_ARG; }
     c->n_tiles = (uint32_t)(c->n_slots / kTile);
     c->hdr_words = exchange_header_words(c->n_ranks);
+    c->hdrb_words = (batch_header_words() + 3) / 4 * 4;
     for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->tok[i], c->cap_slots * 2));
     HIPCHK(hipMalloc(&c->sums, (size_t)c->n_tiles * sizeof(TileSum)));
     HIPCHK(hipMalloc(&c->side, (size_t)c->n_tiles * sizeof(TileSum)));
     HIPCHK(hipMalloc(&c->chg, ((size_t)c->n_tiles / 32 + 2) * 4));
     HIPCHK(hipMemsetAsync(c->chg, 0, ((size_t)c->n_tiles / 32 + 2) * 4, c->stream));
     HIPCHK(hipMalloc(&c->offsets, (size_t)c->n_tiles * 8));
-    const size_t xb_words = (size_t)c->hdr_words + 2 * (size_t)vocab_size + 8;
+    const size_t xb_words = (size_t)c->hdr_words + c->hdrb_words + 2 * (size_t)kBatchMax * vocab_size + 8;
     const size_t xb0_words = 65536 + (size_t)c->hdr_words;
     HIPCHK(hipMalloc(&c->xb, xb_words * 4));
     HIPCHK(hipMalloc(&c->xb0, xb0_words * 4));
     HIPCHK(hipMemsetAsync(c->xb, 0, xb_words * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->xb0, 0, xb0_words * 4, c->stream));
-    c->LR = c->xb + c->hdr_words;
+    c->hdr_m = c->xb + c->hdr_words;
+    c->hdr_adj = c->hdr_m + kBatchMax;
+    c->LR = c->xb + c->hdr_words + c->hdrb_words;
+    HIPCHK(hipMalloc(&c->bs, sizeof(BatchState)));
+    HIPCHK(hipMemsetAsync(c->bs, 0, sizeof(BatchState), c->stream));
+    c->k_upper = 0;
     c->bp = nullptr;   // the byte-pair table lives at the front of xb0
     HIPCHK(hipMalloc(&c->d_left, sizeof(RankEdge)));
     HIPCHK(hipMalloc(&c->d_right, sizeof(RankEdge)));
@@ -557,10 +571,10 @@ static void step_local(mbpe_ctx *c, int ev_slot) {
     const bool multi = is_multi(c);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     launch_merge(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best + c->k, X, endbit, c->LR,
-                 c->ctl, multi ? c->d_left : nullptr, multi ? c->d_right : nullptr, c->n_cus);
+                 c->ctl, &c->ctl->m, multi ? c->d_left : nullptr, multi ? c->d_right : nullptr, c->n_cus, 0);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
     if (multi) {
-        launch_patch_sums(c->stream, c->best + c->k, c->sums, c->side, c->chg, c->n_tiles);
+        launch_patch_sums(c->stream, c->best + c->k, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 0);
         launch_rank_edge(c->stream, c->sums, c->n_tiles, reinterpret_cast<RankEdge *>(c->xb + 2) + c->rank, c->ctl,
                          c->xb);
     }
@@ -570,14 +584,71 @@ static void step_finish(mbpe_ctx *c) {
     const uint32_t X = 256 + c->k;
     const bool multi = is_multi(c);
     launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->LR, multi ? c->xb : nullptr, c->sums, c->side,
-                 c->chg, c->n_tiles);
+                 c->chg, c->n_tiles, 0);
     if (multi) launch_compose_edges(c->stream, c->xb, c->rank, c->n_ranks, c->d_left, c->d_right);
     launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1, use_hier(c));
     c->k++;
 }
 
-// words of xb a merge has to exchange: header + LR entries of the ids that exist (x < X)
-static size_t step_exchange_words(const mbpe_ctx *c) { return (size_t)c->hdr_words + 2 * (size_t)(256 + c->k); }
+// words of xb a merge has to exchange: both headers + the LR cells of the ids that exist (x < X)
+static size_t exchange_words(const mbpe_ctx *c, uint32_t id_upper) {
+    return (size_t)c->hdr_words + c->hdrb_words + 2 * (size_t)kBatchMax * id_upper;
+}
+static size_t step_exchange_words(const mbpe_ctx *c) { return exchange_words(c, 256 + c->k); }
+
+// ---- batch sequences: select -> (single pair: fused merge | several pairs: scan, validate, rewrite) ----
+// The merge counter lives on the device (ctl->k_done); the host only keeps an
+// upper bound (k_upper) between synchronisations.
+
+static inline bool use_batches(const mbpe_ctx *c) { return c->opt_multi_merge != 0; }
+
+static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exchange
+    const uint32_t endbit = c->chunked ? kEndBit : 0;
+    const bool multi = is_multi(c);
+    const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
+    launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->best, c->n_target, (uint32_t)c->opt_max_batch);
+    if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
+    launch_merge(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
+                 multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1);
+    launch_scan_batch(c->stream, c->tok[c->cur], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
+                      c->ctl, le, re, endbit, c->n_cus);
+    if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
+}
+
+static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge exchange
+    const uint32_t endbit = c->chunked ? kEndBit : 0;
+    const bool multi = is_multi(c);
+    const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
+    c->k_upper = std::min<uint32_t>(c->n_target, c->k_upper + (uint32_t)c->opt_max_batch);
+    const uint32_t id_upper = 256 + c->k_upper;
+    launch_batch_tables(c->stream, c->tab, c->ctl, c->bs, c->hdr_m, c->hdr_adj, c->LR, id_upper);
+    launch_apply(c->stream, c->tab, c->ctl, c->best, id_upper, c->LR, multi ? c->xb : nullptr, c->sums, c->side,
+                 c->chg, c->n_tiles, 1);
+    launch_rewrite_marked(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->bs, c->ctl, le, re,
+                          endbit, c->n_cus);
+    launch_patch_sums(c->stream, c->best, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 1);
+    launch_seq_finish(c->stream, c->ctl);
+    if (multi)
+        launch_rank_edge(c->stream, c->sums, c->n_tiles, reinterpret_cast<RankEdge *>(c->xb + 2) + c->rank, c->ctl,
+                         c->xb);
+}
+
+static void seq_stage_c(mbpe_ctx *c) {                   // after the edge exchange
+    if (is_multi(c)) launch_compose_edges(c->stream, c->xb, c->rank, c->n_ranks, c->d_left, c->d_right);
+}
+
+// table entries one sequence can add at most
+static uint64_t seq_headroom(const mbpe_ctx *c) {
+    return (uint64_t)c->opt_max_batch * (2ull * c->vocab_size + kBatchMax + 1);
+}
+
+// sequences between two host synchronisations: bounded by the "batch" option and by
+// the table headroom they need (8M entries at most)
+static uint32_t seqs_per_sync(const mbpe_ctx *c) {
+    uint64_t g = (8ull << 20) / seq_headroom(c);
+    g = std::max<uint64_t>(1, std::min<uint64_t>(g, (uint64_t)c->opt_batch));
+    return (uint32_t)g;
+}
 
 static int comm_allreduce(mbpe_ctx *c, uint32_t *buf, size_t count);   // RCCL (below)
 
@@ -622,6 +693,67 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     return begin_finish(c);
 }
 
+// the batch-sequence loop of mbpe_train_steps (one GPU, or several over RCCL)
+static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
+    const uint32_t start = c->k;
+    const uint32_t target = std::min<uint32_t>(c->n_target, c->k + n_steps);
+    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->ctl->k_limit), (int)target, 1, c->stream));
+    while (c->k < target && !c->exhausted) {
+        const uint32_t group = seqs_per_sync(c);
+        if ((uint64_t)c->h_ctl.n_entries + seq_headroom(c) * group > c->tab.ecap) {
+            int rc = grow_table(c, ((uint64_t)c->h_ctl.n_entries + seq_headroom(c) * group) * 2);
+            if (rc != MBPE_OK) return rc;
+        }
+        if (c->opt_time_kernels) {
+            while (c->kev.size() < 2ull * group) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));
+                c->kev.push_back(e);
+            }
+        }
+        c->k_upper = c->k;
+        const uint32_t batches_before = c->h_ctl.n_batches;
+        HIPCHK(hipEventRecord(c->ev0, c->stream));
+        uint32_t launched = 0;
+        for (uint32_t g = 0; g < group && c->k_upper < target; ++g, ++launched) {
+            seq_stage_a(c, c->opt_time_kernels ? (int)g : -1);
+            if (is_multi(c)) {
+                int rc = comm_allreduce(c, c->xb, exchange_words(c, 256 + std::min<uint32_t>(
+                                                      c->n_target, c->k_upper + (uint32_t)c->opt_max_batch)));
+                if (rc != MBPE_OK) return rc;
+            }
+            seq_stage_b(c);
+            if (is_multi(c)) {
+                int rc = comm_allreduce(c, c->xb, c->hdr_words);
+                if (rc != MBPE_OK) return rc;
+            }
+            seq_stage_c(c);
+        }
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        int rc = sync_ctl(c);
+        if (rc != MBPE_OK) return rc;
+        HIPCHK(hipGetLastError());
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->stats.ms_steps += ms;
+        if (c->opt_time_kernels) {
+            for (uint32_t g = 0; g < launched; ++g) {
+                float km = 0;
+                HIPCHK(hipEventElapsedTime(&km, c->kev[2 * g], c->kev[2 * g + 1]));
+                c->stats.ms_merge_kernel += km;
+            }
+            c->stats.merge_launches += c->h_ctl.n_batches - batches_before;   // sequences that did work
+        }
+        const uint32_t before = c->k;
+        c->k = c->h_ctl.k_done;
+        rc = after_batch(c);
+        if (rc != MBPE_OK) return rc;
+        if (c->k == before) break;      // nothing left to merge
+    }
+    if (steps_done_out) *steps_done_out = c->k - start;
+    return MBPE_OK;
+}
+
 int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
     if (steps_done_out) *steps_done_out = 0;
     if (!c) return MBPE_ERR_ARG;
@@ -629,17 +761,30 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
     if (c->pending) { mbpe_host::set_last_error("an exchange is pending: call mbpe_comm_exchange_done"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
     if (is_multi(c) && c->comm_external) {
-        // one merge per round trip: local part now, the rest in mbpe_comm_exchange_done
+        // one sequence (or one merge) per round trip: local part now, the rest in mbpe_comm_exchange_done
         if (n_steps == 0 || c->k >= c->n_target || c->exhausted) return MBPE_OK;
+        c->pending_target = std::min<uint32_t>(c->n_target, c->k + n_steps);
+        if (use_batches(c)) {
+            HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->ctl->k_limit), (int)c->pending_target, 1,
+                                     c->stream));
+            if ((uint64_t)c->h_ctl.n_entries + seq_headroom(c) > c->tab.ecap) {
+                int rc = grow_table(c, ((uint64_t)c->h_ctl.n_entries + seq_headroom(c)) * 2);
+                if (rc != MBPE_OK) return rc;
+            }
+            c->k_upper = c->k;
+            seq_stage_a(c, -1);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->pending = 3;
+            return MBPE_NEED_EXCHANGE;
+        }
         int rc = before_batch(c, 1);
         if (rc != MBPE_OK) return rc;
-        c->pending_steps = std::min<uint32_t>(n_steps, c->n_target - c->k);
-        c->pending_done = 0;
         step_local(c, -1);
         HIPCHK(hipStreamSynchronize(c->stream));
         c->pending = 2;
         return MBPE_NEED_EXCHANGE;
     }
+    if (use_batches(c)) return train_steps_batched(c, n_steps, steps_done_out);
     uint32_t done = 0;
     while (done < n_steps && c->k < c->n_target && !c->exhausted) {
         uint32_t batch = std::min<uint32_t>({(uint32_t)c->opt_batch, n_steps - done, c->n_target - c->k});
@@ -686,8 +831,16 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
 
 int mbpe_comm_exchange_buffer(mbpe_ctx *c, void **dev_ptr_out, uint64_t *n_u32_out) {
     if (!c || !dev_ptr_out || !n_u32_out) return MBPE_ERR_ARG;
-    if (c->pending == 1) { *dev_ptr_out = c->xb0; *n_u32_out = 65536 + (uint64_t)c->hdr_words; return MBPE_OK; }
-    if (c->pending == 2) { *dev_ptr_out = c->xb; *n_u32_out = step_exchange_words(c); return MBPE_OK; }
+    switch (c->pending) {
+    case 1: *dev_ptr_out = c->xb0; *n_u32_out = 65536 + (uint64_t)c->hdr_words; return MBPE_OK;
+    case 2: *dev_ptr_out = c->xb; *n_u32_out = step_exchange_words(c); return MBPE_OK;
+    case 3:     // deltas of a batch sequence
+        *dev_ptr_out = c->xb;
+        *n_u32_out = exchange_words(c, 256 + std::min<uint32_t>(c->n_target, c->k + (uint32_t)c->opt_max_batch));
+        return MBPE_OK;
+    case 4: *dev_ptr_out = c->xb; *n_u32_out = c->hdr_words; return MBPE_OK;   // rank edges
+    default: break;
+    }
     mbpe_host::set_last_error("no exchange pending");
     return MBPE_ERR_STATE;
 }
@@ -705,15 +858,44 @@ int mbpe_comm_exchange_done(mbpe_ctx *c) {
         int rc = sync_ctl(c);
         if (rc != MBPE_OK) return rc;
         HIPCHK(hipGetLastError());
-        c->pending_done++;
         rc = after_batch(c);
         if (rc != MBPE_OK) return rc;
-        if (c->pending_done < c->pending_steps && c->k < c->n_target) {
+        if (c->k < c->pending_target) {
             rc = before_batch(c, 1);
             if (rc != MBPE_OK) return rc;
             step_local(c, -1);
             HIPCHK(hipStreamSynchronize(c->stream));
             c->pending = 2;
+            return MBPE_NEED_EXCHANGE;
+        }
+        return MBPE_OK;
+    }
+    if (c->pending == 3) {
+        c->pending = 0;
+        seq_stage_b(c);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->pending = 4;
+        return MBPE_NEED_EXCHANGE;
+    }
+    if (c->pending == 4) {
+        c->pending = 0;
+        seq_stage_c(c);
+        int rc = sync_ctl(c);
+        if (rc != MBPE_OK) return rc;
+        HIPCHK(hipGetLastError());
+        const uint32_t before = c->k;
+        c->k = c->h_ctl.k_done;
+        rc = after_batch(c);
+        if (rc != MBPE_OK) return rc;
+        if (c->k < c->pending_target && c->k != before) {
+            if ((uint64_t)c->h_ctl.n_entries + seq_headroom(c) > c->tab.ecap) {
+                rc = grow_table(c, ((uint64_t)c->h_ctl.n_entries + seq_headroom(c)) * 2);
+                if (rc != MBPE_OK) return rc;
+            }
+            c->k_upper = c->k;
+            seq_stage_a(c, -1);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->pending = 3;
             return MBPE_NEED_EXCHANGE;
         }
         return MBPE_OK;

@@ -116,23 +116,36 @@ def test_train_tiny_inputs(tr, data, vocab):
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
-def _step_parity(tr, data, off, vocab, **opts):
-    """Every step: chosen pair, count, live stream, chunk ends and the whole pair table."""
+def _step_parity(tr, data, off, vocab, stride=1, **opts):
+    """After every `stride` merges (1 = every step; larger values let several independent
+    merges share one stream pass): chosen pairs, counts, live stream, chunk ends, pair table."""
     for k, v in opts.items():
         tr.set_option(k, v)
     try:
         st = O.State(data, off)
         tr.load_corpus(data, off)
         tr.train_begin(vocab)
-        for i in range(vocab - 256):
-            top = st.top()
-            done = tr.train_steps(1)
-            if top is None:
+        i = 0
+        rng = np.random.default_rng(len(data) + vocab)
+        while i < vocab - 256:
+            want = 1 if stride == 1 else int(rng.integers(1, stride + 1))
+            want = min(want, vocab - 256 - i)
+            tops = []
+            for j in range(want):
+                top = st.top()
+                if top is None:
+                    break
+                tops.append(top)
+                st.merge(top[0], top[1], 256 + i + j)
+            done = tr.train_steps(want)
+            if not tops:
                 assert done == 0 or len(tr.train_result()[0]) == 0
                 break
+            assert done == len(tops)
             m, c = tr.train_result()
-            assert (int(m[i][0]), int(m[i][1]), int(c[i])) == top, "step %d" % i
-            st.merge(top[0], top[1], 256 + i)
+            for j, top in enumerate(tops):
+                assert (int(m[i + j][0]), int(m[i + j][1]), int(c[i + j])) == top, "step %d" % (i + j)
+            i += len(tops) - 1
             want_toks, want_clen = st.stream()
             toks, ends = tr.stream()
             assert np.array_equal(toks, want_toks), "stream differs at step %d" % i
@@ -144,6 +157,7 @@ def _step_parity(tr, data, off, vocab, **opts):
             want_tab = {k_: v_ for k_, v_ in st.table_dict().items() if v_}
             got_tab = {k_: v_ for k_, v_ in tr.pairs_dict().items() if v_}
             assert got_tab == want_tab, "pair table differs at step %d" % i
+            i += 1
     finally:
         tr.set_option("compact_den", 8)
         tr.set_option("batch", 64)
@@ -255,3 +269,35 @@ def test_hier_argmax_text_zero_counts(tr):
         assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
     finally:
         tr.set_option("hier_argmax", -1)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_batched_merges_parity_random_bytes(tr, seed):
+    # several independent merges per stream pass: compare stream + table at random strides
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.integers(2000, 60000))
+    data = rng.integers(0, int(rng.choice([8, 40, 256])), size=n, dtype=np.uint8)
+    data[0] = max(int(data[0]), 1)
+    _step_parity(tr, data, None, 256 + 120, stride=int(rng.choice([3, 7, 16, 40])),
+                 compact_den=int(rng.choice([0, 3, 8, 50])))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_batched_merges_parity_chunked_text(tr, seed):
+    data = read_data("taylorswift.txt")[seed * 20000:seed * 20000 + 40000]
+    off = mbpe.presplit(O.GPT4_SPLIT_PATTERN if seed % 2 else O.GPT2_SPLIT_PATTERN, data)
+    _step_parity(tr, data, off, 256 + 150, stride=25)
+
+
+def test_batched_vs_single_merge_mode(tr):
+    data = O.splitmix64_bytes(77, 1 << 19)
+    want_m, want_c = O.train(data, 256 + 400)
+    for mode, mb in ((0, 16), (1, 16), (1, 2), (1, 5)):
+        tr.set_option("multi_merge", mode)
+        tr.set_option("max_batch", mb)
+        try:
+            m, c, st = tr.train_lexical(data, 256 + 400)
+        finally:
+            tr.set_option("multi_merge", 1)
+            tr.set_option("max_batch", 16)
+        assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist(), (mode, mb)
