@@ -969,6 +969,61 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 // marked tiles.  A batch of one pair (always valid) takes the fused single
 // pass k_merge instead.
 
+// Lookup tables of a batch in LDS: is (first, second) one of the batch pairs?
+//   tab_f[first & 2047]  = first  << 16 | mask of the classes of its partners
+//   tab_s[second & 2047] = second << 16 | 1 << class(second)
+// (class = index among the distinct second elements, at most kBatchMax).  The
+// test is two LDS reads per slot whatever the batch size.  k_select_batch keeps
+// the tables collision-free: a candidate whose token shares a table slot with
+// a different token of the batch ends the batch.
+constexpr uint32_t kLutSize = 2048;
+
+struct BatchLut {
+    uint32_t tab_f[kLutSize];
+    uint32_t tab_s[kLutSize];
+    uint32_t kk[kBatchMax];      // pair keys as (first | second << 16)
+};
+
+__device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys) {
+    for (uint32_t i = threadIdx.x; i < kLutSize; i += blockDim.x) {
+        lut.tab_f[i] = 0xFFFF0000u;     // token 0xFFFF (a hole) never matches
+        lut.tab_s[i] = 0xFFFF0000u;
+    }
+    if (threadIdx.x < kBatchMax) {
+        const uint32_t key = threadIdx.x < n_keys ? bs->key[threadIdx.x] : 0xFFFFFFFFu;
+        lut.kk[threadIdx.x] = key == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((key >> 16) | (key << 16));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n_cls = 0;
+        for (uint32_t j = 0; j < n_keys; ++j) {
+            const uint32_t a = lut.kk[j] & 0xFFFFu, b = lut.kk[j] >> 16;
+            uint32_t bit;
+            const uint32_t es = lut.tab_s[b & (kLutSize - 1)];
+            if ((es >> 16) == b) bit = es & 0xFFFFu;
+            else { bit = 1u << n_cls++; lut.tab_s[b & (kLutSize - 1)] = (b << 16) | bit; }
+            const uint32_t ef = lut.tab_f[a & (kLutSize - 1)];
+            lut.tab_f[a & (kLutSize - 1)] = (a << 16) | (((ef >> 16) == a ? ef & 0xFFFFu : 0u) | bit);
+        }
+    }
+    __syncthreads();
+}
+
+// is (first, second) a batch pair?  first must be the raw slot value (chunk-end
+// bit clear), second the id of the next live token
+__device__ __forceinline__ bool lut_test(const BatchLut &lut, uint32_t first, uint32_t second) {
+    const uint32_t ef = lut.tab_f[first & (kLutSize - 1)], es = lut.tab_s[second & (kLutSize - 1)];
+    return (ef >> 16) == first && (es >> 16) == second && (ef & es & 0xFFFFu) != 0u;
+}
+
+// index of the pair (only called for pairs that passed lut_test)
+__device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t n_keys, uint32_t first, uint32_t second) {
+    const uint32_t key = first | (second << 16);
+    int r = -1;
+    for (uint32_t j = 0; j < n_keys; ++j) r = lut.kk[j] == key ? (int)j : r;
+    return r;
+}
+
 __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevCtl *ctl, BatchState *bs,
                                                                unsigned long long *best, uint32_t n_target,
                                                                uint32_t max_batch) {
@@ -1033,6 +1088,9 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
             for (uint32_t i = 0; i < accepted; ++i) {
                 const uint32_t ai = s_keys[i] >> 16, bi = s_keys[i] & 0xFFFFu;
                 conflict |= (b == ai) || (a == bi);
+                // lookup-table slots are private to one token
+                conflict |= ai != a && (ai & (kLutSize - 1)) == (a & (kLutSize - 1));
+                conflict |= bi != b && (bi & (kLutSize - 1)) == (b & (kLutSize - 1));
             }
             if (conflict) break;
         }
@@ -1110,18 +1168,11 @@ __device__ __forceinline__ Neigh tile_neighbours(const uint32_t s[8], const Halo
     return nb;
 }
 
-// index of the batch pair with this key, or -1
-__device__ __forceinline__ int find_pair(const uint32_t *keys, uint32_t n_keys, uint32_t key) {
-    int r = -1;
-    for (uint32_t j = 0; j < n_keys; ++j) r = keys[j] == key ? (int)j : r;
-    return r;
-}
-
 // The counting half of a multi-pair merge on one tile: deltas per pair and the
 // tile's mark.  Nothing is rewritten.
 template <bool CHUNKED>
 __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, const uint32_t s[8], const Halo h,
-                                               const uint32_t *keys, uint32_t n_keys, uint32_t *hdr_m,
+                                               const BatchLut &lut, uint32_t n_keys, uint32_t *hdr_m,
                                                uint32_t *hdr_adj, uint32_t *LR) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
@@ -1133,24 +1184,22 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
         const uint32_t self = s[j];
         if (self == kHole) continue;
         const uint32_t n1 = nb.n1v[j], n2 = nb.n2v[j];
-        const int ja = n1 == kHole ? -1 : find_pair(keys, n_keys, self | ((n1 & idmask) << 16));
-        if (ja >= 0) {                       // first token of a match of pair ja
-            any = true;
-            atomicAdd(&hdr_m[ja], 1u);
+        if (lut_test(lut, self, n1 & idmask)) {          // first token of a match
+            const int ja = lut_index(lut, n_keys, self, n1 & idmask);
+            any = true;                                  // (the number of matches of a pair is its count)
             if (p1 != kHole && !(p1 & endbit)) {
-                const int jp = p2 == kHole ? -1 : find_pair(keys, n_keys, p2 | (p1 << 16));
-                if (jp >= 0) atomicAdd(&hdr_adj[jp * kBatchMax + ja], 1u);     // two matches touch
-                else atomicAdd(&LR[lr_idx(p1, (uint32_t)ja, 0)], 1u);
-            }
-        } else {
-            const int jb = p1 == kHole ? -1 : find_pair(keys, n_keys, p1 | ((self & idmask) << 16));
-            if (jb >= 0) {                   // second token of a match of pair jb
-                any = true;
-                if (!(self & endbit) && n1 != kHole) {
-                    const int jn = n2 == kHole ? -1 : find_pair(keys, n_keys, n1 | ((n2 & idmask) << 16));
-                    if (jn < 0) atomicAdd(&LR[lr_idx(n1 & idmask, (uint32_t)jb, 1)], 1u);
+                if (lut_test(lut, p2, p1)) {                 // two matches touch
+                    const int jp = lut_index(lut, n_keys, p2, p1);
+                    atomicAdd(&hdr_adj[jp * kBatchMax + ja], 1u);
+                } else {
+                    atomicAdd(&LR[lr_idx(p1, (uint32_t)ja, 0)], 1u);
                 }
             }
+        } else if (lut_test(lut, p1, self & idmask)) {    // second token of a match
+            const int jb = lut_index(lut, n_keys, p1, self & idmask);
+            any = true;
+            if (!(self & endbit) && n1 != kHole && !lut_test(lut, n1, n2 & idmask))
+                atomicAdd(&LR[lr_idx(n1 & idmask, (uint32_t)jb, 1)], 1u);
         }
         p2 = p1; p1 = self;
     }
@@ -1165,21 +1214,15 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__
                                                               const DevCtl *ctl, const RankEdge *le,
                                                               const RankEdge *re) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    __shared__ BatchLut lut;
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
-    uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
-    if (tile >= n_tiles) return;
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2) return;
-    // pair keys, also as (first | second << 16): the layout of a slot and its successor
-    __shared__ uint32_t s_keys[kBatchMax], s_kk[kBatchMax];
-    if (threadIdx.x < kBatchMax) {
-        const uint32_t key = threadIdx.x < n_keys ? bs->key[threadIdx.x] : 0xFFFFFFFFu;
-        s_keys[threadIdx.x] = key;
-        s_kk[threadIdx.x] = key == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((key >> 16) | (key << 16));
-    }
-    __syncthreads();
+    lut_build(lut, bs, n_keys);
+    uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
+    if (tile >= n_tiles) return;
 
     const uint32_t last_tile = n_tiles - 1;
     auto clamp_tile = [&](uint64_t t) { return (uint32_t)(t < n_tiles ? t : last_tile); };
@@ -1217,27 +1260,16 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__
             const unsigned long long hi = m_live & gt_mask;
             const uint32_t nf = __shfl(lf, hi ? (uint32_t)__builtin_ctzll(hi) : lane, kWave);
             uint32_t c = hi ? nf : h.n1;
-            uint32_t acc = 0xFFFFFFFFu;
+            bool cand = false;
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                const uint32_t key = s[j] | ((CHUNKED ? (c & idmask) : c) << 16);
-                if (n_keys <= 4) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const uint32_t x = key ^ s_kk[q]; acc = x < acc ? x : acc; }
-                } else if (n_keys <= 8) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { const uint32_t x = key ^ s_kk[q]; acc = x < acc ? x : acc; }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < kBatchMax; ++q) { const uint32_t x = key ^ s_kk[q]; acc = x < acc ? x : acc; }
-                }
+                cand |= lut_test(lut, s[j], c & idmask);
                 c = s[j] != kHole ? s[j] : c;
             }
-            bool work = __ballot(acc == 0u) != 0ull;
-            if (!work && h.p1 != kHole) {      // a match whose first token is the previous tile's last
-                for (uint32_t q = 0; q < n_keys; ++q) work |= (s_keys[q] >> 16) == h.p1;
-            }
-            if (work) scan_tile_full<CHUNKED>(chg, tile, s, h, s_kk, n_keys, hdr_m, hdr_adj, LR);
+            // (also: a match whose first token is the previous tile's last live token)
+            const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
+            const bool work = __ballot(cand) != 0ull || lut_test(lut, h.p1, tile_first & idmask);
+            if (work) scan_tile_full<CHUNKED>(chg, tile, s, h, lut, n_keys, hdr_m, hdr_adj, LR);
         }
         if (!v1) break;
         tile += n_waves;
@@ -1341,12 +1373,10 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
             }
         }
     }
-    if (gid < (uint64_t)kBatchMax) {
-        const uint32_t m = hdr_m[gid];
-        if (m) {
-            hdr_m[gid] = 0;
-            if (gid < commit) table_add(t, ctl, bs->key[gid], -(int32_t)m, false);
-        }
+    if (gid < commit) {
+        // every occurrence of an (a,b), a != b, pair is merged: its count drops to 0
+        const uint32_t m = (uint32_t)(bs->packed[gid] >> 32);
+        if (m) table_add(t, ctl, bs->key[gid], -(int32_t)m, false);
     }
 }
 
@@ -1360,29 +1390,36 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *__re
                                                                   const RankEdge *re) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    __shared__ BatchLut lut;
     if (ctl->batch_n < 2) return;
     const uint32_t n_keys = ctl->commit_n;
     const uint32_t X0 = 256u + ctl->k_done;
-    __shared__ uint32_t s_kk[kBatchMax];
-    if (threadIdx.x < kBatchMax) {
-        const uint32_t key = bs->key[threadIdx.x];
-        s_kk[threadIdx.x] = threadIdx.x < n_keys ? ((key >> 16) | (key << 16)) : 0xFFFFFFFFu;
-    }
-    __syncthreads();
+    lut_build(lut, bs, n_keys);
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
     const uint32_t n_words = (n_tiles + 31u) / 32u;
+    const __amdgpu_buffer_rsrc_t sums_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
     uint32_t wave_rm = 0;
     for (uint32_t w = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave); w < n_words; w += n_waves) {
         uint32_t bits = chg[w];
         while (bits) {
             const uint32_t tile = w * 32u + (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1;
-            const uint4 q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kWave + lane];
+            const TileIn t0 = tile_issue(tok, sums_rsrc, tile);
             uint32_t s[8];
-            unpack8(q, s);
-            const Halo h = halo_slow(sin, n_tiles, tile, le, re);
+            unpack8(t0.q, s);
+            Halo h;
+            const uint32_t pw1 = rlane(t0.sm.y, 0), pw2 = rlane(t0.sm.z, 0);
+            const uint32_t nw0 = rlane(t0.sm.x, 2), nw2 = rlane(t0.sm.z, 2);
+            const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
+            if (fast) {
+                h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
+                h.n1 = nw0 & 0xFFFFu; h.n2 = nw0 >> 16;
+            } else {
+                h = halo_slow(sin, n_tiles, tile, le, re);
+            }
             const Neigh nb = tile_neighbours(s, h);
             bool changed = false;
             uint32_t p1 = nb.p1_in, my_rm = 0;
@@ -1391,11 +1428,10 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *__re
                 const uint32_t self = s[j];
                 if (self == kHole) continue;
                 const uint32_t n1 = nb.n1v[j];
-                const int ja = n1 == kHole ? -1 : find_pair(s_kk, n_keys, self | ((n1 & idmask) << 16));
-                if (ja >= 0) {
-                    s[j] = (X0 + (uint32_t)ja) | (n1 & endbit);
+                if (lut_test(lut, self, n1 & idmask)) {
+                    s[j] = (X0 + (uint32_t)lut_index(lut, n_keys, self, n1 & idmask)) | (n1 & endbit);
                     changed = true;
-                } else if (p1 != kHole && find_pair(s_kk, n_keys, p1 | ((self & idmask) << 16)) >= 0) {
+                } else if (lut_test(lut, p1, self & idmask)) {
                     s[j] = kHole;
                     changed = true;
                     ++my_rm;
