@@ -1045,31 +1045,44 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     uint32_t accepted = 0;
+    // Bounds and the entries of the block under inspection are cached in
+    // registers (thread t owns super-block t, block (cur_S, t) and entry
+    // (cur_B, t)), so a round costs LDS reductions plus at most one global load.
+    unsigned long long sb = tid < n_super ? ld(&t.smax[tid]) : 0ull;
+    unsigned long long bb = 0;
+    uint32_t cur_S = 0xFFFFFFFFu, cur_B = 0xFFFFFFFFu, e_key = kEmptyKey;
+    int32_t e_cnt = 0;
     for (uint32_t k = 0; k < limit; ++k) {
         // hierarchical argmax over the entries that are not yet in the batch
         unsigned long long cand = 0;
         uint32_t cand_idx = 0;
         for (int round = 0; round < 1 << 20; ++round) {
-            const Top2 ts = block_top2(tid < n_super ? ld(&t.smax[tid]) : 0ull, tid, sh);
+            const Top2 ts = block_top2(sb, tid, sh);
             if (ts.v1 == 0ull) break;
             const uint32_t S = ts.i1;
             const uint32_t bidx = (S << kBlockShift) + tid;
-            const Top2 tb = block_top2(bidx < n_blocks ? ld(&t.bmax[bidx]) : 0ull, bidx, sh);
+            if (S != cur_S) { cur_S = S; bb = bidx < n_blocks ? ld(&t.bmax[bidx]) : 0ull; }
+            const Top2 tb = block_top2(bb, bidx, sh);
             const uint32_t B = tb.i1;
             const uint32_t e = (B << kBlockShift) + tid;
+            if (B != cur_B) {
+                cur_B = B;
+                e_cnt = e < n ? t.ecnt[e] : 0;
+                e_key = e < n ? t.ekey[e] : kEmptyKey;
+            }
             unsigned long long p = 0;
             if (e < n) {
-                const int32_t c = t.ecnt[e];
-                const uint32_t key = t.ekey[e];
                 // a pair already in the batch will have count 0 once it is merged (a != b):
                 // it stays a (zero-count) candidate, SURVEY 8-S rule 4
                 bool excluded = false;
-                for (uint32_t i = 0; i < accepted; ++i) excluded |= s_keys[i] == key;
-                p = pack_best(excluded || c < 0 ? 0 : c, key);
+                for (uint32_t i = 0; i < accepted; ++i) excluded |= s_keys[i] == e_key;
+                p = pack_best(excluded || e_cnt < 0 ? 0 : e_cnt, e_key);
             }
             const Top2 te = block_top2(p, e, sh);
             const unsigned long long truth = te.v1;
             const unsigned long long s_bound = truth > tb.v2 ? truth : tb.v2;
+            if (bidx == B) bb = truth;
+            if (tid == S) sb = s_bound;
             if (tid == 0) {
                 // (lowered below an accepted entry's count: k_validate restores the bounds of
                 //  accepted pairs that end up not being merged)
@@ -1077,7 +1090,6 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
                 __hip_atomic_store(&t.smax[S], s_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (truth >= tb.v2 && truth >= ts.v2) { cand = truth; cand_idx = te.i1; break; }
-            __syncthreads();
         }
         if (cand == 0ull) break;
         const uint32_t count = (uint32_t)(cand >> 32), key = ~(uint32_t)cand;
