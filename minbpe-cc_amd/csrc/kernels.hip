@@ -981,13 +981,19 @@ constexpr uint32_t kLutSize = 2048;
 struct BatchLut {
     uint32_t tab_f[kLutSize];
     uint32_t tab_s[kLutSize];
+    uint32_t bloom[2048];        // 65,536-bit filter over hashed (first, second): one read per slot
     uint32_t kk[kBatchMax];      // pair keys as (first | second << 16)
 };
+
+__device__ __forceinline__ uint32_t pair_hash(uint32_t first, uint32_t second) {
+    return (first * 40503u + second) & 0xFFFFu;
+}
 
 __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys) {
     for (uint32_t i = threadIdx.x; i < kLutSize; i += blockDim.x) {
         lut.tab_f[i] = 0xFFFF0000u;     // token 0xFFFF (a hole) never matches
         lut.tab_s[i] = 0xFFFF0000u;
+        lut.bloom[i] = 0;
     }
     if (threadIdx.x < kBatchMax) {
         const uint32_t key = threadIdx.x < n_keys ? bs->key[threadIdx.x] : 0xFFFFFFFFu;
@@ -1004,9 +1010,17 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
             else { bit = 1u << n_cls++; lut.tab_s[b & (kLutSize - 1)] = (b << 16) | bit; }
             const uint32_t ef = lut.tab_f[a & (kLutSize - 1)];
             lut.tab_f[a & (kLutSize - 1)] = (a << 16) | (((ef >> 16) == a ? ef & 0xFFFFu : 0u) | bit);
+            const uint32_t h = pair_hash(a, b);
+            lut.bloom[h >> 5] |= 1u << (h & 31u);
         }
     }
     __syncthreads();
+}
+
+// cheap superset test (no false negatives): one LDS read
+__device__ __forceinline__ bool bloom_test(const BatchLut &lut, uint32_t first, uint32_t second) {
+    const uint32_t h = pair_hash(first, second);
+    return (lut.bloom[h >> 5] >> (h & 31u)) & 1u;
 }
 
 // is (first, second) a batch pair?  first must be the raw slot value (chunk-end
@@ -1275,7 +1289,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__
             bool cand = false;
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                cand |= lut_test(lut, s[j], c & idmask);
+                cand |= bloom_test(lut, s[j], c & idmask);      // superset; the full path is exact
                 c = s[j] != kHole ? s[j] : c;
             }
             // (also: a match whose first token is the previous tile's last live token)
@@ -1296,12 +1310,25 @@ __global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, con
     if (n_keys < 2) return;
     const uint32_t X = 256u + ctl->k_done;
     const uint64_t total = (uint64_t)X * kBatchMax;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t j = (uint32_t)(i % kBatchMax);
-        if (j >= n_keys) continue;
-        const uint2 lr = reinterpret_cast<const uint2 *>(LR)[i];
-        if (lr.x) atomicMax(&bs->max_l[j], lr.x);
-        if (lr.y) atomicMax(&bs->max_r[j], lr.y);
+    // the stride is a multiple of kBatchMax, so a thread only ever sees one pair index j
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = (uint32_t)(gid % kBatchMax);
+    uint32_t ml = 0, mr = 0;
+    if (j < n_keys)
+        for (uint64_t i = gid; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+            const uint2 lr = reinterpret_cast<const uint2 *>(LR)[i];
+            ml = lr.x > ml ? lr.x : ml;
+            mr = lr.y > mr ? lr.y : mr;
+        }
+    // lanes l, l+16, l+32, l+48 share j
+    for (int d = 32; d >= 16; d >>= 1) {
+        const uint32_t ol = __shfl_xor(ml, d, kWave), orr = __shfl_xor(mr, d, kWave);
+        ml = ol > ml ? ol : ml;
+        mr = orr > mr ? orr : mr;
+    }
+    if (lane_id() < (uint32_t)kBatchMax && j < n_keys) {
+        if (ml) atomicMax(&bs->max_l[j], ml);
+        if (mr) atomicMax(&bs->max_r[j], mr);
     }
 }
 
@@ -1773,7 +1800,7 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     uint32_t blocks = (uint32_t)((cells + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 2) blocks = 2;
-    hipLaunchKernelGGL(k_delta_max, dim3(blocks), dim3(256), 0, s, LR, bs, ctl);
+    hipLaunchKernelGGL(k_delta_max, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, LR, bs, ctl);
     hipLaunchKernelGGL(k_validate, dim3(1), dim3(64), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     hipLaunchKernelGGL(k_apply_batch, dim3(blocks), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
 }
