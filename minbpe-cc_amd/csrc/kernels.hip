@@ -1420,72 +1420,103 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
 }
 
 // The rewriting half: tiles marked by the scan pass, pairs of the validated prefix.
+// k_list_marked turns the bitmap into a dense list so that k_rewrite_marked can
+// walk it with the same prefetch ring as the streaming passes.
+__global__ void k_list_marked(const uint32_t *__restrict__ chg, uint32_t n_words, uint32_t *__restrict__ list,
+                              DevCtl *ctl) {
+    if (ctl->batch_n < 2) return;
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bits = w < n_words ? chg[w] : 0u;
+    const uint32_t cnt = __popc(bits);
+    const uint32_t incl = wave_incl_scan(cnt);
+    const uint32_t total = __shfl(incl, kWave - 1, kWave);
+    uint32_t base = 0;
+    if (lane_id() == 0 && total) base = atomicAdd(&ctl->n_marked, total);
+    base = __shfl(base, 0, kWave) + incl - cnt;
+    while (bits) {
+        list[base++] = w * 32u + (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1;
+    }
+}
+
 template <bool CHUNKED>
 __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *__restrict__ tok,
                                                                   const TileSum *__restrict__ sin,
                                                                   TileSum *__restrict__ sout, uint32_t n_tiles,
-                                                                  uint32_t *__restrict__ chg, const BatchState *bs,
-                                                                  DevCtl *ctl, const RankEdge *le,
-                                                                  const RankEdge *re) {
+                                                                  uint32_t *__restrict__ chg,
+                                                                  const uint32_t *__restrict__ list,
+                                                                  const BatchState *bs, DevCtl *ctl,
+                                                                  const RankEdge *le, const RankEdge *re) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     __shared__ BatchLut lut;
     if (ctl->batch_n < 2) return;
     const uint32_t n_keys = ctl->commit_n;
     const uint32_t X0 = 256u + ctl->k_done;
+    const uint32_t n_list = ctl->n_marked;
     lut_build(lut, bs, n_keys);
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
-    const uint32_t n_words = (n_tiles + 31u) / 32u;
+    uint32_t i = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
+    if (i >= n_list) return;
     const __amdgpu_buffer_rsrc_t sums_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
+    const uint32_t last = n_list - 1;
+    auto tile_at = [&](uint64_t k) { return list[k < n_list ? k : last]; };
+    uint32_t tile0 = tile_at(i), tile1 = tile_at((uint64_t)i + n_waves), tile2 = tile_at((uint64_t)i + 2ull * n_waves);
+    TileIn t0 = tile_issue(tok, sums_rsrc, tile0);
+    TileIn t1 = tile_issue(tok, sums_rsrc, tile1);
     uint32_t wave_rm = 0;
-    for (uint32_t w = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave); w < n_words; w += n_waves) {
-        uint32_t bits = chg[w];
-        while (bits) {
-            const uint32_t tile = w * 32u + (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1;
-            const TileIn t0 = tile_issue(tok, sums_rsrc, tile);
-            uint32_t s[8];
-            unpack8(t0.q, s);
-            Halo h;
-            const uint32_t pw1 = rlane(t0.sm.y, 0), pw2 = rlane(t0.sm.z, 0);
-            const uint32_t nw0 = rlane(t0.sm.x, 2), nw2 = rlane(t0.sm.z, 2);
-            const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
-            if (fast) {
-                h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
-                h.n1 = nw0 & 0xFFFFu; h.n2 = nw0 >> 16;
-            } else {
-                h = halo_slow(sin, n_tiles, tile, le, re);
-            }
-            const Neigh nb = tile_neighbours(s, h);
-            bool changed = false;
-            uint32_t p1 = nb.p1_in, my_rm = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t self = s[j];
-                if (self == kHole) continue;
-                const uint32_t n1 = nb.n1v[j];
-                if (lut_test(lut, self, n1 & idmask)) {
-                    s[j] = (X0 + (uint32_t)lut_index(lut, n_keys, self, n1 & idmask)) | (n1 & endbit);
-                    changed = true;
-                } else if (lut_test(lut, p1, self & idmask)) {
-                    s[j] = kHole;
-                    changed = true;
-                    ++my_rm;
-                }
-                p1 = self;
-            }
-            if (changed) reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
-            wave_rm += my_rm;
-            if (__ballot(changed) != 0ull) {
-                const uint4 ns = wave_summary(s);
-                if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
-            } else if (lane == 0) {
-                atomicAnd(&chg[w], ~(1u << (tile & 31u)));    // marked for a pair that was dropped
-            }
+    for (;;) {
+        const bool has_next = (uint64_t)i + n_waves < n_list;
+        const uint32_t tile3 = tile_at((uint64_t)i + 3ull * n_waves);
+        const TileIn t2 = tile_issue(tok, sums_rsrc, tile2);
+
+        const uint32_t tile = tile0;
+        uint32_t s[8];
+        unpack8(t0.q, s);
+        Halo h;
+        const uint32_t pw1 = rlane(t0.sm.y, 0), pw2 = rlane(t0.sm.z, 0);
+        const uint32_t nw0 = rlane(t0.sm.x, 2), nw2 = rlane(t0.sm.z, 2);
+        const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
+        if (fast) {
+            h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
+            h.n1 = nw0 & 0xFFFFu; h.n2 = nw0 >> 16;
+        } else {
+            h = halo_slow(sin, n_tiles, tile, le, re);
         }
+        const Neigh nb = tile_neighbours(s, h);
+        bool changed = false;
+        uint32_t p1 = nb.p1_in, my_rm = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t self = s[j];
+            if (self == kHole) continue;
+            const uint32_t n1 = nb.n1v[j];
+            if (lut_test(lut, self, n1 & idmask)) {
+                s[j] = (X0 + (uint32_t)lut_index(lut, n_keys, self, n1 & idmask)) | (n1 & endbit);
+                changed = true;
+            } else if (lut_test(lut, p1, self & idmask)) {
+                s[j] = kHole;
+                changed = true;
+                ++my_rm;
+            }
+            p1 = self;
+        }
+        if (changed) reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
+        wave_rm += my_rm;
+        if (__ballot(changed) != 0ull) {
+            const uint4 ns = wave_summary(s);
+            if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
+        } else if (lane == 0) {
+            atomicAnd(&chg[tile >> 5], ~(1u << (tile & 31u)));    // marked for a pair that was dropped
+        }
+
+        if (!has_next) break;
+        i += n_waves;
+        tile0 = tile1; tile1 = tile2; tile2 = tile3;
+        t0 = t1; t1 = t2;
     }
     const uint32_t tr = wave_sum(wave_rm);
     if (lane == 0 && tr) atomicAdd(&ctl->rm, tr);
@@ -1503,6 +1534,7 @@ __global__ void k_seq_finish(DevCtl *ctl) {
     ctl->k_done += ctl->commit_n;
     ctl->batch_n = 0;
     ctl->commit_n = 0;
+    ctl->n_marked = 0;
 }
 
 // ---- compaction ---------------------------------------------------------------------
@@ -1806,17 +1838,18 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 }
 
 void launch_rewrite_marked(hipStream_t s, uint16_t *tok, const TileSum *sums, TileSum *side, uint32_t n_tiles,
-                           uint32_t *chg, const BatchState *bs, DevCtl *ctl, const RankEdge *left_edge,
-                           const RankEdge *right_edge, uint32_t endbit, int n_cus) {
+                           uint32_t *chg, uint32_t *list, const BatchState *bs, DevCtl *ctl,
+                           const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus) {
     if (!n_tiles) return;
     const uint32_t n_words = (n_tiles + 31u) / 32u;
-    const dim3 grid(tile_grid(n_words, n_cus)), block(kMergeThreads);
+    hipLaunchKernelGGL(k_list_marked, dim3((n_words + 255) / 256), dim3(256), 0, s, chg, n_words, list, ctl);
+    const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
     if (endbit)
-        hipLaunchKernelGGL(k_rewrite_marked<true>, grid, block, 0, s, tok, sums, side, n_tiles, chg, bs, ctl, left_edge,
-                           right_edge);
+        hipLaunchKernelGGL(k_rewrite_marked<true>, grid, block, 0, s, tok, sums, side, n_tiles, chg, list, bs, ctl,
+                           left_edge, right_edge);
     else
-        hipLaunchKernelGGL(k_rewrite_marked<false>, grid, block, 0, s, tok, sums, side, n_tiles, chg, bs, ctl, left_edge,
-                           right_edge);
+        hipLaunchKernelGGL(k_rewrite_marked<false>, grid, block, 0, s, tok, sums, side, n_tiles, chg, list, bs, ctl,
+                           left_edge, right_edge);
 }
 
 void launch_seq_finish(hipStream_t s, DevCtl *ctl) {

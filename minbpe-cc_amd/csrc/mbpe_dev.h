@@ -80,6 +80,7 @@ struct DevCtl {
     uint32_t batch_n;        // candidates selected for the current batch (0: nothing to do)
     uint32_t commit_n;       // how many of them survive validation
     uint32_t n_batches;      // batches that did work (statistics)
+    uint32_t n_marked;       // tiles in the rewrite list of the current batch
 };
 
 // A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
@@ -165,8 +166,8 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const TileSum *sums, 
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                          uint32_t *LR, uint32_t id_upper);
 void launch_rewrite_marked(hipStream_t s, uint16_t *tok, const TileSum *sums, TileSum *side, uint32_t n_tiles,
-                           uint32_t *chg, const BatchState *bs, DevCtl *ctl, const RankEdge *left_edge,
-                           const RankEdge *right_edge, uint32_t endbit, int n_cus);
+                           uint32_t *chg, uint32_t *list /* [n_tiles] scratch */, const BatchState *bs, DevCtl *ctl,
+                           const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus);
 void launch_seq_finish(hipStream_t s, DevCtl *ctl);
 
 // compaction: exclusive scan of n_live over tiles, then scatter

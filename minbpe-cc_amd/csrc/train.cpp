@@ -134,6 +134,7 @@ struct mbpe_ctx {
     TileSum *sums = nullptr;     // live tile summaries
     TileSum *side = nullptr;     // staging for the tiles a merge pass changed
     uint32_t *chg = nullptr;     // bitmap of those tiles
+    uint32_t *tile_list = nullptr;   // the same as a dense list (batch rewrite pass)
     unsigned long long *offsets = nullptr;
 
     // pair table
@@ -200,7 +201,7 @@ int sync_ctl(mbpe_ctx *c) {
 
 void free_training(mbpe_ctx *c) {
     dfree(c->tok[0]); dfree(c->tok[1]);
-    dfree(c->sums); dfree(c->side); dfree(c->chg);
+    dfree(c->sums); dfree(c->side); dfree(c->chg); dfree(c->tile_list);
     dfree(c->offsets);
     dfree(c->tab.hkey); dfree(c->tab.hidx); dfree(c->tab.ekey); dfree(c->tab.ecnt);
     dfree(c->tab.bmax); dfree(c->tab.smax);
@@ -499,6 +500,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(hipMalloc(&c->sums, (size_t)c->n_tiles * sizeof(TileSum)));
     HIPCHK(hipMalloc(&c->side, (size_t)c->n_tiles * sizeof(TileSum)));
     HIPCHK(hipMalloc(&c->chg, ((size_t)c->n_tiles / 32 + 2) * 4));
+    HIPCHK(hipMalloc(&c->tile_list, ((size_t)c->n_tiles + 64) * 4));
     HIPCHK(hipMemsetAsync(c->chg, 0, ((size_t)c->n_tiles / 32 + 2) * 4, c->stream));
     HIPCHK(hipMalloc(&c->offsets, (size_t)c->n_tiles * 8));
     const size_t xb_words = (size_t)c->hdr_words + c->hdrb_words + 2 * (size_t)kBatchMax * vocab_size + 8;
@@ -624,7 +626,7 @@ static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge excha
     launch_batch_tables(c->stream, c->tab, c->ctl, c->bs, c->hdr_m, c->hdr_adj, c->LR, id_upper);
     launch_apply(c->stream, c->tab, c->ctl, c->best, id_upper, c->LR, multi ? c->xb : nullptr, c->sums, c->side,
                  c->chg, c->n_tiles, 1);
-    launch_rewrite_marked(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->bs, c->ctl, le, re,
+    launch_rewrite_marked(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->tile_list, c->bs, c->ctl, le, re,
                           endbit, c->n_cus);
     launch_patch_sums(c->stream, c->best, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 1);
     launch_seq_finish(c->stream, c->ctl);
