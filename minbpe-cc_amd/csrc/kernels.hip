@@ -1194,45 +1194,62 @@ __device__ __forceinline__ Neigh tile_neighbours(const uint32_t s[8], const Halo
     return nb;
 }
 
+// exact membership with the one-read filter in front
+__device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, uint32_t second) {
+    return bloom_test(lut, first, second) && lut_test(lut, first, second);
+}
+
 // The counting half of a multi-pair merge on one tile: deltas per pair and the
-// tile's mark.  Nothing is rewritten.
-template <bool CHUNKED>
+// tile's mark.  Nothing is rewritten.  Batch pairs cannot overlap (no token is
+// both a first and a second element), so "this token is the second of a match"
+// is simply "the previous live token started a match": one membership test per
+// live slot, everything else only where a match is.
+template <bool CHUNKED, int DIAG = 0>
 __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, const uint32_t s[8], const Halo h,
-                                               const BatchLut &lut, uint32_t n_keys, uint32_t *hdr_m,
-                                               uint32_t *hdr_adj, uint32_t *LR) {
+                                               const BatchLut &lut, uint32_t n_keys, uint32_t *hdr_adj,
+                                               uint32_t *LR) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     const Neigh nb = tile_neighbours(s, h);
     bool any = false;
     uint32_t p1 = nb.p1_in, p2 = nb.p2_in;
+    bool a1 = false;       // p1 started a match (so the current token is its second element)
+    bool first = true;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t self = s[j];
         if (self == kHole) continue;
         const uint32_t n1 = nb.n1v[j], n2 = nb.n2v[j];
-        if (lut_test(lut, self, n1 & idmask)) {          // first token of a match
+        if (first) { a1 = p1 != kHole && pair_test(lut, p1, self & idmask); first = false; }
+        bool is_a = false;
+        if (a1) {                                        // second token of a match of pair (p1, self)
+            any = true;
+            if (!(self & endbit) && n1 != kHole && !pair_test(lut, n1, n2 & idmask)) {
+                const int jb = lut_index(lut, n_keys, p1, self & idmask);
+                if (DIAG != 3) atomicAdd(&LR[lr_idx(n1 & idmask, (uint32_t)jb, 1)], 1u);
+                else asm volatile("" :: "v"(jb));
+            }
+        } else if (n1 != kHole && pair_test(lut, self, n1 & idmask)) {   // first token of a match
+            is_a = true;
+            any = true;
             const int ja = lut_index(lut, n_keys, self, n1 & idmask);
-            any = true;                                  // (the number of matches of a pair is its count)
             if (p1 != kHole && !(p1 & endbit)) {
-                if (lut_test(lut, p2, p1)) {                 // two matches touch
+                if (p2 != kHole && pair_test(lut, p2, p1)) {               // two matches touch
                     const int jp = lut_index(lut, n_keys, p2, p1);
                     atomicAdd(&hdr_adj[jp * kBatchMax + ja], 1u);
                 } else {
-                    atomicAdd(&LR[lr_idx(p1, (uint32_t)ja, 0)], 1u);
+                    if (DIAG != 3) atomicAdd(&LR[lr_idx(p1, (uint32_t)ja, 0)], 1u);
+                    else asm volatile("" :: "v"(ja));
                 }
             }
-        } else if (lut_test(lut, p1, self & idmask)) {    // second token of a match
-            const int jb = lut_index(lut, n_keys, p1, self & idmask);
-            any = true;
-            if (!(self & endbit) && n1 != kHole && !lut_test(lut, n1, n2 & idmask))
-                atomicAdd(&LR[lr_idx(n1 & idmask, (uint32_t)jb, 1)], 1u);
         }
+        a1 = is_a;
         p2 = p1; p1 = self;
     }
     if (__ballot(any) != 0ull && lane_id() == 0) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
 }
 
-template <bool CHUNKED>
+template <bool CHUNKED, int DIAG = 0>
 __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__restrict__ tok,
                                                               const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                               uint32_t *__restrict__ chg, const BatchState *bs,
@@ -1264,7 +1281,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__
         TileIn t3 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 3ull * n_waves));
 
         const uint32_t me_nlive = rlane(t0.sm.z, 1) & 0xFFFFu;
-        if (me_nlive != 0) {
+        if (DIAG == 1) {
+            asm volatile("" :: "v"(t0.q.x), "v"(t0.q.y), "v"(t0.q.z), "v"(t0.q.w), "v"(t0.sm.x), "v"(t0.sm.y));
+        } else if (me_nlive != 0) {
             uint32_t s[8];
             unpack8(t0.q, s);
             Halo h;
@@ -1294,8 +1313,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__
             }
             // (also: a match whose first token is the previous tile's last live token)
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
-            const bool work = __ballot(cand) != 0ull || lut_test(lut, h.p1, tile_first & idmask);
-            if (work) scan_tile_full<CHUNKED>(chg, tile, s, h, lut, n_keys, hdr_m, hdr_adj, LR);
+            bool work = __ballot(cand) != 0ull || lut_test(lut, h.p1, tile_first & idmask);
+            if (DIAG == 2) { asm volatile("" :: "v"((uint32_t)cand)); work = false; }
+            if (work) scan_tile_full<CHUNKED, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR);
         }
         if (!v1) break;
         tile += n_waves;
@@ -1487,21 +1507,25 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *__re
             h = halo_slow(sin, n_tiles, tile, le, re);
         }
         const Neigh nb = tile_neighbours(s, h);
-        bool changed = false;
+        bool changed = false, a1 = false, first = true;
         uint32_t p1 = nb.p1_in, my_rm = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint32_t self = s[j];
             if (self == kHole) continue;
             const uint32_t n1 = nb.n1v[j];
-            if (lut_test(lut, self, n1 & idmask)) {
-                s[j] = (X0 + (uint32_t)lut_index(lut, n_keys, self, n1 & idmask)) | (n1 & endbit);
-                changed = true;
-            } else if (lut_test(lut, p1, self & idmask)) {
+            if (first) { a1 = p1 != kHole && pair_test(lut, p1, self & idmask); first = false; }
+            bool is_a = false;
+            if (a1) {                      // second token of a match: becomes a hole
                 s[j] = kHole;
                 changed = true;
                 ++my_rm;
+            } else if (n1 != kHole && pair_test(lut, self, n1 & idmask)) {
+                is_a = true;
+                s[j] = (X0 + (uint32_t)lut_index(lut, n_keys, self, n1 & idmask)) | (n1 & endbit);
+                changed = true;
             }
+            a1 = is_a;
             p1 = self;
         }
         if (changed) reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
@@ -1817,11 +1841,29 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const TileSum *sums, 
                        const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus) {
     if (!n_tiles) return;
     const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
+#ifdef MBPE_DIAG
+    static const int diag = getenv("MBPE_SCAN_DIAG") ? atoi(getenv("MBPE_SCAN_DIAG")) : 0;
+    if (diag == 1 && !endbit) {
+        hipLaunchKernelGGL((k_scan_batch<false, 1>), grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+                           ctl, left_edge, right_edge);
+        return;
+    }
+    if (diag == 2 && !endbit) {
+        hipLaunchKernelGGL((k_scan_batch<false, 2>), grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+                           ctl, left_edge, right_edge);
+        return;
+    }
+    if (diag == 3 && !endbit) {
+        hipLaunchKernelGGL((k_scan_batch<false, 3>), grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+                           ctl, left_edge, right_edge);
+        return;
+    }
+#endif
     if (endbit)
-        hipLaunchKernelGGL(k_scan_batch<true>, grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+        hipLaunchKernelGGL((k_scan_batch<true, 0>), grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge);
     else
-        hipLaunchKernelGGL(k_scan_batch<false>, grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+        hipLaunchKernelGGL((k_scan_batch<false, 0>), grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge);
 }
 
