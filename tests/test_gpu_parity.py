@@ -301,3 +301,31 @@ def test_batched_vs_single_merge_mode(tr):
             tr.set_option("multi_merge", 1)
             tr.set_option("max_batch", 16)
         assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist(), (mode, mb)
+
+
+def test_large_corpus_properties(tr):
+    """256 MiB of SplitMix64 bytes, 600 merges (tens of stream passes, compaction, table growth):
+    size-independent properties instead of an oracle run --
+      * chosen counts never increase (new pairs are bounded by the pair they came from),
+      * expanding the final stream through the merges gives back the corpus' byte histogram
+        and length (nothing lost, nothing duplicated),
+      * the first merges equal the oracle's on the pair table of the whole corpus."""
+    n = 256 << 20
+    data = O.splitmix64_bytes(42, n)
+    tr.set_option("compact_den", 64)
+    try:
+        m, c, st = tr.train_lexical(data, 256 + 600)
+    finally:
+        tr.set_option("compact_den", 8)
+    assert len(m) == 600 and np.all(np.diff(c) <= 0)
+    table = O.pair_count_u8(data)
+    first = int(np.argmax(table))                      # ties resolve to the smallest key, like the trainer
+    assert (int(m[0][0]), int(m[0][1])) == (first >> 8, first & 0xFF) and int(c[0]) == int(table[first])
+    toks, _ = tr.stream()
+    assert st["n_live"] == len(toks) and st["n_compactions"] >= 1
+    occ = np.bincount(toks, minlength=256 + 600).astype(np.int64)
+    hist = np.zeros((256 + 600, 256), dtype=np.int64)   # byte histogram of every token
+    hist[np.arange(256), np.arange(256)] = 1
+    for k, (a, b) in enumerate(m):
+        hist[256 + k] = hist[int(a)] + hist[int(b)]
+    assert np.array_equal(occ @ hist, np.bincount(data, minlength=256).astype(np.int64))
