@@ -312,7 +312,7 @@ def test_large_corpus_properties(tr):
       * the first merges equal the oracle's on the pair table of the whole corpus."""
     n = 256 << 20
     data = O.splitmix64_bytes(42, n)
-    tr.set_option("compact_den", 64)
+    tr.set_option("compact_den", 400)      # compact when holes reach 1/400 of the slots
     try:
         m, c, st = tr.train_lexical(data, 256 + 600)
     finally:
