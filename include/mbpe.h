@@ -70,7 +70,7 @@ typedef struct {
     uint32_t pair_count_launches;
     uint32_t merge_launches;   /* merge-kernel launches timed ("time_kernels" option) */
     float    ms_merge_kernel;  /* summed duration of those launches */
-    uint32_t reserved;
+    uint32_t n_batches;        /* stream passes that merged something (several merges can share one) */
 } mbpe_stats;
 
 MBPE_API const char *mbpe_last_error(void);

@@ -932,6 +932,7 @@ int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
     c->stats.n_live = c->begun ? c->h_ctl.n_live : 0;
     c->stats.n_merges = c->exhausted ? 0 : c->n_valid;
     c->stats.n_pairs = c->begun ? c->h_ctl.n_entries : 0;
+    c->stats.n_batches = c->begun ? (use_batches(c) ? c->h_ctl.n_batches : c->k) : 0;
     *out = c->stats;
     return MBPE_OK;
 }

@@ -40,7 +40,7 @@ class Stats(ctypes.Structure):
         ("n_live", ctypes.c_uint64), ("n_merges", ctypes.c_uint32), ("n_compactions", ctypes.c_uint32),
         ("n_pairs", ctypes.c_uint64), ("ms_pair_count", ctypes.c_float), ("ms_begin", ctypes.c_float),
         ("ms_steps", ctypes.c_float), ("pair_count_launches", ctypes.c_uint32), ("merge_launches", ctypes.c_uint32),
-        ("ms_merge_kernel", ctypes.c_float), ("reserved", ctypes.c_uint32),
+        ("ms_merge_kernel", ctypes.c_float), ("n_batches", ctypes.c_uint32),
     ]
 
     def as_dict(self):
