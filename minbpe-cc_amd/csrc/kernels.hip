@@ -92,28 +92,31 @@ __device__ __forceinline__ uint32_t hash_key(uint32_t k) {
 __device__ void table_add(const PairTable &t, DevCtl *ctl, uint32_t key, int32_t delta, bool may_insert) {
     uint32_t h = hash_key(key) & t.hmask;
     for (uint32_t probe = 0; probe <= t.hmask; ++probe) {
-        uint32_t k = t.hkey[h];
-        if (k == key) {
-            int32_t old = atomicAdd(&t.ecnt[t.hidx[h]], delta);
+        const unsigned long long slot = t.hslot[h];
+        if ((uint32_t)(slot >> 32) == key) {
+            int32_t old = atomicAdd(&t.ecnt[(uint32_t)slot], delta);
             if (old + delta < 0) atomicOr(&ctl->err, kErrNegCount);
             return;
         }
-        if (k == kEmptyKey) {
+        if (slot == kEmptySlot) {
             if (!may_insert) { atomicOr(&ctl->err, kErrMissingPair); return; }
-            uint32_t prev = atomicCAS(&t.hkey[h], kEmptyKey, key);
-            if (prev == kEmptyKey) {
+            // claim the slot with the key; the index follows (nobody looks this key up in this kernel)
+            const unsigned long long claim = ((unsigned long long)key << 32) | 0xFFFFFFFFull;
+            const unsigned long long prev = atomicCAS(&t.hslot[h], kEmptySlot, claim);
+            if (prev == kEmptySlot) {
                 uint32_t idx = atomicAdd(&ctl->n_entries, 1u);
                 if (idx >= t.ecap) { atomicOr(&ctl->err, kErrTableFull); return; }
-                t.hidx[h] = idx;
+                reinterpret_cast<uint32_t *>(&t.hslot[h])[0] = idx;     // low word (little endian)
                 t.ekey[idx] = key;
                 t.ecnt[idx] = delta;
-                // upper bounds for the hierarchical argmax (counts only fall after insertion)
+                // upper bounds for the hierarchical argmax (counts only fall after insertion);
+                // entries are appended, so a block's bound is usually already higher: read first
                 const unsigned long long p = pack_best(delta, key);
-                atomicMax(&t.bmax[idx >> kBlockShift], p);
-                atomicMax(&t.smax[idx >> (2 * kBlockShift)], p);
+                if (p > t.bmax[idx >> kBlockShift]) atomicMax(&t.bmax[idx >> kBlockShift], p);
+                if (p > t.smax[idx >> (2 * kBlockShift)]) atomicMax(&t.smax[idx >> (2 * kBlockShift)], p);
                 return;
             }
-            if (prev == key) {  // cannot happen by construction; keep the table sane anyway
+            if ((uint32_t)(prev >> 32) == key) {  // cannot happen by construction; keep the table sane anyway
                 atomicOr(&ctl->err, kErrMissingPair);
                 return;
             }
@@ -583,9 +586,10 @@ __global__ void k_table_rehash(PairTable t, DevCtl *ctl) {
     if (i >= ctl->n_entries) return;
     uint32_t key = t.ekey[i];
     uint32_t h = hash_key(key) & t.hmask;
+    const unsigned long long slot = ((unsigned long long)key << 32) | i;
     for (;;) {
-        uint32_t prev = atomicCAS(&t.hkey[h], kEmptyKey, key);
-        if (prev == kEmptyKey) { t.hidx[h] = i; return; }
+        const unsigned long long prev = atomicCAS(&t.hslot[h], kEmptySlot, slot);
+        if (prev == kEmptySlot) return;
         h = (h + 1) & t.hmask;
     }
 }

@@ -44,18 +44,19 @@ struct RankEdge {
 };
 
 // ---- pair table ---------------------------------------------------------
-// Open-addressing hash (key -> entry index) plus dense entry arrays that the
+// Open-addressing hash (key -> entry index; key and index share one 8-byte slot, so
+// a probe is one memory access) plus dense entry arrays that the
 // argmax kernel scans.  key = (first << 16) | second.  Entries are never
 // removed: PairCountLexicalOrder never erases (PairCount.h:249-260), so a
 // pair whose count returned to 0 is still a candidate (SURVEY.md 8-S rule 4).
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
+constexpr unsigned long long kEmptySlot = 0xFFFFFFFFFFFFFFFFull;
 
 constexpr int kBlockShift = 10;                 // argmax hierarchy: 1024 entries per block,
 constexpr uint32_t kBlockSize = 1u << kBlockShift;   // 1024 blocks per super-block
 
 struct PairTable {
-    uint32_t *hkey;      // [hcap] kEmptyKey when free
-    uint32_t *hidx;      // [hcap] index into ekey/ecnt
+    unsigned long long *hslot;   // [hcap] (key << 32) | entry index; kEmptySlot when free
     uint32_t *ekey;      // [ecap]
     int32_t  *ecnt;      // [ecap]
     unsigned long long *bmax;   // [ecap / 1024 + 1] upper bound of packed (count, ~key) per block

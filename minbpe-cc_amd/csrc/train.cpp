@@ -203,7 +203,7 @@ void free_training(mbpe_ctx *c) {
     dfree(c->tok[0]); dfree(c->tok[1]);
     dfree(c->sums); dfree(c->side); dfree(c->chg); dfree(c->tile_list);
     dfree(c->offsets);
-    dfree(c->tab.hkey); dfree(c->tab.hidx); dfree(c->tab.ekey); dfree(c->tab.ecnt);
+    dfree(c->tab.hslot); dfree(c->tab.ekey); dfree(c->tab.ecnt);
     dfree(c->tab.bmax); dfree(c->tab.smax);
     dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->xb); dfree(c->xb0);
     dfree(c->d_left); dfree(c->d_right); dfree(c->bs);
@@ -225,8 +225,7 @@ int alloc_table(mbpe_ctx *c, uint32_t ecap) {
     c->tab.ecap = ecap;
     c->hcap = next_pow2((uint64_t)ecap * 2);
     c->tab.hmask = c->hcap - 1;
-    HIPCHK(hipMalloc(&c->tab.hkey, (size_t)c->hcap * 4));
-    HIPCHK(hipMalloc(&c->tab.hidx, (size_t)c->hcap * 4));
+    HIPCHK(hipMalloc(&c->tab.hslot, (size_t)c->hcap * 8));
     HIPCHK(hipMalloc(&c->tab.ekey, (size_t)ecap * 4));
     HIPCHK(hipMalloc(&c->tab.ecnt, (size_t)ecap * 4));
     const size_t nb = ((size_t)ecap >> kBlockShift) + 2, ns = ((size_t)ecap >> (2 * kBlockShift)) + 2;
@@ -234,7 +233,7 @@ int alloc_table(mbpe_ctx *c, uint32_t ecap) {
     HIPCHK(hipMalloc(&c->tab.smax, ns * 8));
     HIPCHK(hipMemsetAsync(c->tab.bmax, 0, nb * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->tab.smax, 0, ns * 8, c->stream));
-    launch_fill_u32(c->stream, c->tab.hkey, c->hcap, kEmptyKey);
+    launch_fill_u32(c->stream, reinterpret_cast<uint32_t *>(c->tab.hslot), (uint64_t)c->hcap * 2, 0xFFFFFFFFu);
     return MBPE_OK;
 }
 
@@ -270,7 +269,7 @@ int grow_table(mbpe_ctx *c, uint64_t want) {
                           hipMemcpyDeviceToDevice, c->stream));
     launch_table_rehash(c->stream, c->tab, c->ctl);
     HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(old.hkey); (void)hipFree(old.hidx); (void)hipFree(old.ekey); (void)hipFree(old.ecnt);
+    (void)hipFree(old.hslot); (void)hipFree(old.ekey); (void)hipFree(old.ecnt);
     (void)hipFree(old.bmax); (void)hipFree(old.smax);
     return MBPE_OK;
 }
