@@ -491,7 +491,8 @@ __global__ __launch_bounds__(kArgmaxThreads) void k_argmax(PairTable t, const De
 // maximum is not below any other bound.  Typically two rounds per merge (the
 // first one hits the block of the pair that was just merged away), whatever
 // the table size.
-constexpr int kHierThreads = 1024;
+constexpr int kHierThreads = 256;                    // 4 waves: the reductions stay cheap
+constexpr int kHierItems = kBlockSize / kHierThreads; // 4 values per thread and level
 
 struct Top2 { unsigned long long v1, v2; uint32_t i1; };
 
@@ -507,9 +508,12 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// largest and second largest of one value per thread over the workgroup (all threads get the result)
-__device__ Top2 block_top2(unsigned long long v, uint32_t idx, Top2 *sh) {
-    Top2 t = {v, 0ull, idx};
+// Largest and second largest of 1024 values over the workgroup (all threads get
+// the result): thread t holds the values of indices base + q * 256 + t, q < 4.
+__device__ Top2 block_top2(const unsigned long long v[kHierItems], uint32_t base, Top2 *sh) {
+    Top2 t = {v[0], 0ull, base + threadIdx.x};
+#pragma unroll
+    for (int q = 1; q < kHierItems; ++q) t = top2_merge(t, v[q], 0ull, base + q * kHierThreads + threadIdx.x);
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
         const unsigned long long o1 = shfl_xor_u64(t.v1, d), o2 = shfl_xor_u64(t.v2, d);
@@ -540,21 +544,34 @@ __global__ __launch_bounds__(kHierThreads) void k_argmax_hier(PairTable t, const
     };
     for (int round = 0; round < 1 << 20; ++round) {   // terminates: every round lowers one bound
         // best and second-best super-block bound (n_super <= 1024: the table is capped at 2^30 entries)
-        const Top2 ts = block_top2(tid < n_super ? ld(&t.smax[tid]) : 0ull, tid, sh);
+        unsigned long long v[kHierItems];
+#pragma unroll
+        for (int q = 0; q < kHierItems; ++q) {
+            const uint32_t i = q * kHierThreads + tid;
+            v[q] = i < n_super ? ld(&t.smax[i]) : 0ull;
+        }
+        const Top2 ts = block_top2(v, 0, sh);
         if (ts.v1 == 0ull) return;
         const uint32_t S = ts.i1;
         // best and second-best block bound inside S
-        const uint32_t bidx = (S << kBlockShift) + tid;
-        const Top2 tb = block_top2(bidx < n_blocks ? ld(&t.bmax[bidx]) : 0ull, bidx, sh);
+#pragma unroll
+        for (int q = 0; q < kHierItems; ++q) {
+            const uint32_t i = (S << kBlockShift) + q * kHierThreads + tid;
+            v[q] = i < n_blocks ? ld(&t.bmax[i]) : 0ull;
+        }
+        const Top2 tb = block_top2(v, S << kBlockShift, sh);
         const uint32_t B = tb.i1;
         // true maximum of block B
-        const uint32_t e = (B << kBlockShift) + tid;
-        unsigned long long p = 0;
-        if (e < n) {
-            const int32_t c = t.ecnt[e];
-            p = pack_best(c < 0 ? 0 : c, t.ekey[e]);
+#pragma unroll
+        for (int q = 0; q < kHierItems; ++q) {
+            const uint32_t e = (B << kBlockShift) + q * kHierThreads + tid;
+            v[q] = 0;
+            if (e < n) {
+                const int32_t c = t.ecnt[e];
+                v[q] = pack_best(c < 0 ? 0 : c, t.ekey[e]);
+            }
         }
-        const Top2 te = block_top2(p, e, sh);
+        const Top2 te = block_top2(v, B << kBlockShift, sh);
         const unsigned long long truth = te.v1;
         const unsigned long long s_bound = truth > tb.v2 ? truth : tb.v2;
         if (tid == 0) {
@@ -1064,43 +1081,68 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
     };
     uint32_t accepted = 0;
     // Bounds and the entries of the block under inspection are cached in
-    // registers (thread t owns super-block t, block (cur_S, t) and entry
-    // (cur_B, t)), so a round costs LDS reductions plus at most one global load.
-    unsigned long long sb = tid < n_super ? ld(&t.smax[tid]) : 0ull;
-    unsigned long long bb = 0;
-    uint32_t cur_S = 0xFFFFFFFFu, cur_B = 0xFFFFFFFFu, e_key = kEmptyKey;
-    int32_t e_cnt = 0;
+    // registers (thread t owns items q * 256 + t of every level), so a round
+    // costs LDS reductions plus at most one global load.
+    unsigned long long sb[kHierItems], bb[kHierItems];
+    uint32_t e_key[kHierItems];
+    int32_t e_cnt[kHierItems];
+#pragma unroll
+    for (int q = 0; q < kHierItems; ++q) {
+        const uint32_t i = q * kHierThreads + tid;
+        sb[q] = i < n_super ? ld(&t.smax[i]) : 0ull;
+        bb[q] = 0;
+        e_key[q] = kEmptyKey;
+        e_cnt[q] = 0;
+    }
+    uint32_t cur_S = 0xFFFFFFFFu, cur_B = 0xFFFFFFFFu;
     for (uint32_t k = 0; k < limit; ++k) {
         // hierarchical argmax over the entries that are not yet in the batch
         unsigned long long cand = 0;
         uint32_t cand_idx = 0;
         for (int round = 0; round < 1 << 20; ++round) {
-            const Top2 ts = block_top2(sb, tid, sh);
+            const Top2 ts = block_top2(sb, 0, sh);
             if (ts.v1 == 0ull) break;
             const uint32_t S = ts.i1;
-            const uint32_t bidx = (S << kBlockShift) + tid;
-            if (S != cur_S) { cur_S = S; bb = bidx < n_blocks ? ld(&t.bmax[bidx]) : 0ull; }
-            const Top2 tb = block_top2(bb, bidx, sh);
+            if (S != cur_S) {
+                cur_S = S;
+#pragma unroll
+                for (int q = 0; q < kHierItems; ++q) {
+                    const uint32_t i = (S << kBlockShift) + q * kHierThreads + tid;
+                    bb[q] = i < n_blocks ? ld(&t.bmax[i]) : 0ull;
+                }
+            }
+            const Top2 tb = block_top2(bb, S << kBlockShift, sh);
             const uint32_t B = tb.i1;
-            const uint32_t e = (B << kBlockShift) + tid;
             if (B != cur_B) {
                 cur_B = B;
-                e_cnt = e < n ? t.ecnt[e] : 0;
-                e_key = e < n ? t.ekey[e] : kEmptyKey;
+#pragma unroll
+                for (int q = 0; q < kHierItems; ++q) {
+                    const uint32_t e = (B << kBlockShift) + q * kHierThreads + tid;
+                    e_cnt[q] = e < n ? t.ecnt[e] : 0;
+                    e_key[q] = e < n ? t.ekey[e] : kEmptyKey;
+                }
             }
-            unsigned long long p = 0;
-            if (e < n) {
-                // a pair already in the batch will have count 0 once it is merged (a != b):
-                // it stays a (zero-count) candidate, SURVEY 8-S rule 4
-                bool excluded = false;
-                for (uint32_t i = 0; i < accepted; ++i) excluded |= s_keys[i] == e_key;
-                p = pack_best(excluded || e_cnt < 0 ? 0 : e_cnt, e_key);
+            unsigned long long p[kHierItems];
+#pragma unroll
+            for (int q = 0; q < kHierItems; ++q) {
+                const uint32_t e = (B << kBlockShift) + q * kHierThreads + tid;
+                p[q] = 0;
+                if (e < n) {
+                    // a pair already in the batch will have count 0 once it is merged (a != b):
+                    // it stays a (zero-count) candidate, SURVEY 8-S rule 4
+                    bool excluded = false;
+                    for (uint32_t i = 0; i < accepted; ++i) excluded |= s_keys[i] == e_key[q];
+                    p[q] = pack_best(excluded || e_cnt[q] < 0 ? 0 : e_cnt[q], e_key[q]);
+                }
             }
-            const Top2 te = block_top2(p, e, sh);
+            const Top2 te = block_top2(p, B << kBlockShift, sh);
             const unsigned long long truth = te.v1;
             const unsigned long long s_bound = truth > tb.v2 ? truth : tb.v2;
-            if (bidx == B) bb = truth;
-            if (tid == S) sb = s_bound;
+#pragma unroll
+            for (int q = 0; q < kHierItems; ++q) {
+                if ((S << kBlockShift) + q * kHierThreads + tid == B) bb[q] = truth;
+                if ((uint32_t)(q * kHierThreads) + tid == S) sb[q] = s_bound;
+            }
             if (tid == 0) {
                 // (lowered below an accepted entry's count: k_validate restores the bounds of
                 //  accepted pairs that end up not being merged)
