@@ -218,8 +218,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("k_merge", args.bytes, args.vocab, world),
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 PMC passes of this workload, early merges)",
+                "traffic": pmc_traffic("k_scan_batch", args.bytes, args.vocab, world),
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 PMC passes of this workload, early passes)",
+                "merges_per_pass": done / max(n_launch, 1),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": avg_kernel_ms,
                 "launches": n_launch,
