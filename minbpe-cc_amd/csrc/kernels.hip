@@ -60,6 +60,15 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(v, d, kWave);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 // sum over all lanes of a per-lane count in [0, 8], via ballots (scalar popcounts)
 __device__ __forceinline__ uint32_t wave_sum_le8(uint32_t v, unsigned long long lane_mask) {
     uint32_t s = 0;
@@ -990,73 +999,56 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 // marked tiles.  A batch of one pair (always valid) takes the fused single
 // pass k_merge instead.
 
-// Lookup tables of a batch in LDS: is (first, second) one of the batch pairs?
-//   tab_f[first & 2047]  = first  << 16 | mask of the classes of its partners
-//   tab_s[second & 2047] = second << 16 | 1 << class(second)
-// (class = index among the distinct second elements, at most kBatchMax).  The
-// test is two LDS reads per slot whatever the batch size.  k_select_batch keeps
-// the tables collision-free: a candidate whose token shares a table slot with
-// a different token of the batch ends the batch.
-constexpr uint32_t kLutSize = 2048;
+// Lookup table of a batch in LDS: is (first, second) one of the batch pairs, and
+// which one?  A hash table of kBuckets buckets of two keys each, keys stored as
+// (first | second << 16): ONE 8-byte LDS read and two compares per test, exact
+// (no false positives), whatever the batch size.  k_select_batch keeps every
+// bucket within its two keys: a candidate that would be the third key of a
+// bucket ends the batch.  0xFFFE is never a token id (MBPE_MAX_VOCAB_*), so
+// kEmptyPair can never be asked for.
+constexpr uint32_t kBuckets = 1024;
+constexpr uint32_t kEmptyPair = 0xFFFEFFFEu;
 
 struct BatchLut {
-    uint32_t tab_f[kLutSize];
-    uint32_t tab_s[kLutSize];
-    uint32_t bloom[2048];        // 65,536-bit filter over hashed (first, second): one read per slot
-    uint32_t kk[kBatchMax];      // pair keys as (first | second << 16)
+    uint2 bucket[kBuckets];
+    uint32_t bidx[kBuckets];     // batch index of bucket.x (low half) and bucket.y (high half)
 };
 
 __device__ __forceinline__ uint32_t pair_hash(uint32_t first, uint32_t second) {
-    return (first * 40503u + second) & 0xFFFFu;
+    return (__umul24(first, 40503u) + second) & (kBuckets - 1u);
 }
 
 __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys) {
-    for (uint32_t i = threadIdx.x; i < kLutSize; i += blockDim.x) {
-        lut.tab_f[i] = 0xFFFF0000u;     // token 0xFFFF (a hole) never matches
-        lut.tab_s[i] = 0xFFFF0000u;
-        lut.bloom[i] = 0;
-    }
-    if (threadIdx.x < kBatchMax) {
-        const uint32_t key = threadIdx.x < n_keys ? bs->key[threadIdx.x] : 0xFFFFFFFFu;
-        lut.kk[threadIdx.x] = key == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((key >> 16) | (key << 16));
+    for (uint32_t i = threadIdx.x; i < kBuckets; i += blockDim.x) {
+        lut.bucket[i] = make_uint2(kEmptyPair, kEmptyPair);
+        lut.bidx[i] = 0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t n_cls = 0;
         for (uint32_t j = 0; j < n_keys; ++j) {
-            const uint32_t a = lut.kk[j] & 0xFFFFu, b = lut.kk[j] >> 16;
-            uint32_t bit;
-            const uint32_t es = lut.tab_s[b & (kLutSize - 1)];
-            if ((es >> 16) == b) bit = es & 0xFFFFu;
-            else { bit = 1u << n_cls++; lut.tab_s[b & (kLutSize - 1)] = (b << 16) | bit; }
-            const uint32_t ef = lut.tab_f[a & (kLutSize - 1)];
-            lut.tab_f[a & (kLutSize - 1)] = (a << 16) | (((ef >> 16) == a ? ef & 0xFFFFu : 0u) | bit);
-            const uint32_t h = pair_hash(a, b);
-            lut.bloom[h >> 5] |= 1u << (h & 31u);
+            const uint32_t key = bs->key[j];
+            const uint32_t a = key >> 16, b = key & 0xFFFFu, h = pair_hash(a, b);
+            const uint32_t kk = a | (b << 16);
+            if (lut.bucket[h].x == kEmptyPair) { lut.bucket[h].x = kk; lut.bidx[h] = j; }
+            else { lut.bucket[h].y = kk; lut.bidx[h] |= j << 16; }
         }
     }
     __syncthreads();
 }
 
-// cheap superset test (no false negatives): one LDS read
-__device__ __forceinline__ bool bloom_test(const BatchLut &lut, uint32_t first, uint32_t second) {
+// is (first, second) a batch pair?  first may be any raw slot value (a hole or a
+// token with the chunk-end bit never matches), second the id of the next live token
+__device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, uint32_t second) {
+    const uint2 bk = lut.bucket[pair_hash(first, second)];
+    const uint32_t kk = first | (second << 16);
+    return bk.x == kk || bk.y == kk;
+}
+
+// index of the pair (only called for pairs that passed pair_test)
+__device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, uint32_t second) {
     const uint32_t h = pair_hash(first, second);
-    return (lut.bloom[h >> 5] >> (h & 31u)) & 1u;
-}
-
-// is (first, second) a batch pair?  first must be the raw slot value (chunk-end
-// bit clear), second the id of the next live token
-__device__ __forceinline__ bool lut_test(const BatchLut &lut, uint32_t first, uint32_t second) {
-    const uint32_t ef = lut.tab_f[first & (kLutSize - 1)], es = lut.tab_s[second & (kLutSize - 1)];
-    return (ef >> 16) == first && (es >> 16) == second && (ef & es & 0xFFFFu) != 0u;
-}
-
-// index of the pair (only called for pairs that passed lut_test)
-__device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t n_keys, uint32_t first, uint32_t second) {
-    const uint32_t key = first | (second << 16);
-    int r = -1;
-    for (uint32_t j = 0; j < n_keys; ++j) r = lut.kk[j] == key ? (int)j : r;
-    return r;
+    const uint32_t ix = lut.bidx[h];
+    return (int)(lut.bucket[h].x == (first | (second << 16)) ? ix & 0xFFFFu : ix >> 16);
 }
 
 __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevCtl *ctl, BatchState *bs,
@@ -1157,14 +1149,13 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
         const bool single = count == 0 || a == b;
         if (k > 0) {
             bool conflict = single;
+            uint32_t same_bucket = 0;
             for (uint32_t i = 0; i < accepted; ++i) {
                 const uint32_t ai = s_keys[i] >> 16, bi = s_keys[i] & 0xFFFFu;
                 conflict |= (b == ai) || (a == bi);
-                // lookup-table slots are private to one token
-                conflict |= ai != a && (ai & (kLutSize - 1)) == (a & (kLutSize - 1));
-                conflict |= bi != b && (bi & (kLutSize - 1)) == (b & (kLutSize - 1));
+                same_bucket += pair_hash(ai, bi) == pair_hash(a, b);
             }
-            if (conflict) break;
+            if (conflict || same_bucket >= 2) break;      // (a lookup bucket holds two keys)
         }
         __syncthreads();
         if (tid == 0) {
@@ -1240,11 +1231,6 @@ __device__ __forceinline__ Neigh tile_neighbours(const uint32_t s[8], const Halo
     return nb;
 }
 
-// exact membership with the one-read filter in front
-__device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, uint32_t second) {
-    return bloom_test(lut, first, second) && lut_test(lut, first, second);
-}
-
 // The counting half of a multi-pair merge on one tile: deltas per pair and the
 // tile's mark.  Nothing is rewritten.  Batch pairs cannot overlap (no token is
 // both a first and a second element), so "this token is the second of a match"
@@ -1271,17 +1257,17 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
         if (a1) {                                        // second token of a match of pair (p1, self)
             any = true;
             if (!(self & endbit) && n1 != kHole && !pair_test(lut, n1, n2 & idmask)) {
-                const int jb = lut_index(lut, n_keys, p1, self & idmask);
+                const int jb = lut_index(lut, p1, self & idmask);
                 if (DIAG != 3) atomicAdd(&LR[lr_idx(n1 & idmask, (uint32_t)jb, 1)], 1u);
                 else asm volatile("" :: "v"(jb));
             }
         } else if (n1 != kHole && pair_test(lut, self, n1 & idmask)) {   // first token of a match
             is_a = true;
             any = true;
-            const int ja = lut_index(lut, n_keys, self, n1 & idmask);
+            const int ja = lut_index(lut, self, n1 & idmask);
             if (p1 != kHole && !(p1 & endbit)) {
                 if (p2 != kHole && pair_test(lut, p2, p1)) {               // two matches touch
-                    const int jp = lut_index(lut, n_keys, p2, p1);
+                    const int jp = lut_index(lut, p2, p1);
                     atomicAdd(&hdr_adj[jp * kBatchMax + ja], 1u);
                 } else {
                     if (DIAG != 3) atomicAdd(&LR[lr_idx(p1, (uint32_t)ja, 0)], 1u);
@@ -1354,12 +1340,12 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__
             bool cand = false;
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                cand |= bloom_test(lut, s[j], c & idmask);      // superset; the full path is exact
+                cand |= pair_test(lut, s[j], c & idmask);
                 c = s[j] != kHole ? s[j] : c;
             }
             // (also: a match whose first token is the previous tile's last live token)
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
-            bool work = __ballot(cand) != 0ull || lut_test(lut, h.p1, tile_first & idmask);
+            bool work = __ballot(cand) != 0ull || pair_test(lut, h.p1, tile_first & idmask);
             if (DIAG == 2) { asm volatile("" :: "v"((uint32_t)cand)); work = false; }
             if (work) scan_tile_full<CHUNKED, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR);
         }
@@ -1386,8 +1372,8 @@ __global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, con
             ml = lr.x > ml ? lr.x : ml;
             mr = lr.y > mr ? lr.y : mr;
         }
-    // lanes l, l+16, l+32, l+48 share j
-    for (int d = 32; d >= 16; d >>= 1) {
+    // lanes l, l + kBatchMax, ... share j
+    for (int d = 32; d >= kBatchMax; d >>= 1) {
         const uint32_t ol = __shfl_xor(ml, d, kWave), orr = __shfl_xor(mr, d, kWave);
         ml = ol > ml ? ol : ml;
         mr = orr > mr ? orr : mr;
@@ -1403,39 +1389,65 @@ __global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, con
 // merges before it can have created.  Then the deltas of the surviving prefix
 // are made exact for "only the prefix is merged", and the argmax bounds of the
 // dropped pairs are restored.
-__global__ void k_validate(PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
-                           uint32_t *LR) {
-    if (blockIdx.x || threadIdx.x) return;
+__global__ __launch_bounds__(256) void k_validate(PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m,
+                                                  uint32_t *hdr_adj, uint32_t *LR) {
+    static_assert(kBatchMax <= kWave, "one wave validates a batch");
+    __shared__ uint32_t s_part[256 / kWave];
+    __shared__ uint32_t s_commit;
+    const uint32_t tid = threadIdx.x;
     const uint32_t n = ctl->batch_n;
     if (n < 2) return;
-    uint32_t commit = n;
-    uint32_t max_adj = 0;
-    for (uint32_t i = 0; i < n * (uint32_t)kBatchMax; ++i) {
-        const uint32_t v = hdr_adj[(i / kBatchMax) * kBatchMax + (i % kBatchMax)];
-        max_adj = v > max_adj ? v : max_adj;
+    uint32_t v = 0;
+    for (uint32_t i = tid; i < n * (uint32_t)kBatchMax; i += blockDim.x) {
+        const uint32_t w = hdr_adj[i];
+        v = w > v ? w : v;
     }
-    unsigned long long bound = 0;     // upper bound of the count of any pair created so far
-    for (uint32_t j = 1; j < n; ++j) {
-        const unsigned long long l = (unsigned long long)bs->max_l[j - 1] + max_adj;
-        const unsigned long long r = (unsigned long long)bs->max_r[j - 1] + max_adj;
-        const unsigned long long u = l > r ? l : r;
-        bound = u > bound ? u : bound;
-        if ((bs->packed[j] >> 32) <= bound) { commit = j; break; }   // ties go to the safe side
-    }
-    // a match of a kept pair that touches a match of a dropped pair keeps its plain neighbour
-    for (uint32_t j = 0; j < commit; ++j)
-        for (uint32_t p = commit; p < n; ++p) {
-            const uint32_t ap = bs->key[p] >> 16, bp = bs->key[p] & 0xFFFFu;
-            const uint32_t in = hdr_adj[p * kBatchMax + j], out = hdr_adj[j * kBatchMax + p];
-            if (in) { LR[lr_idx(bp, j, 0)] += in; hdr_adj[p * kBatchMax + j] = 0; }
-            if (out) { LR[lr_idx(ap, j, 1)] += out; hdr_adj[j * kBatchMax + p] = 0; }
+    v = wave_max_u32(v);
+    if (lane_id() == 0) s_part[tid / kWave] = v;
+    __syncthreads();
+    if (tid < (uint32_t)kWave) {
+        uint32_t max_adj = 0;
+        for (uint32_t w = 0; w < 256 / kWave; ++w) max_adj = s_part[w] > max_adj ? s_part[w] : max_adj;
+        // u_j = upper bound of the count of any pair merge j creates; pair j survives iff its
+        // count beats max(u_0 .. u_{j-1}) (ties go to the safe side)
+        unsigned long long u = 0;
+        if (tid < n) {
+            const unsigned long long l = (unsigned long long)bs->max_l[tid] + max_adj;
+            const unsigned long long r = (unsigned long long)bs->max_r[tid] + max_adj;
+            u = l > r ? l : r;
         }
-    for (uint32_t p = commit; p < n; ++p) {
-        const uint32_t e = bs->eidx[p];
-        atomicMax(&t.bmax[e >> kBlockShift], bs->packed[p]);
-        atomicMax(&t.smax[e >> (2 * kBlockShift)], bs->packed[p]);
+        unsigned long long run = u;         // inclusive prefix maximum
+        for (int d = 1; d < kWave; d <<= 1) {
+            const unsigned long long o = __shfl_up(run, d, kWave);
+            if ((int)tid >= d) run = o > run ? o : run;
+        }
+        const unsigned long long before = __shfl_up(run, 1, kWave);
+        const bool fails = tid >= 1 && tid < n && (bs->packed[tid] >> 32) <= before;
+        const unsigned long long fm = __ballot(fails);
+        if (tid == 0) s_commit = fm ? (uint32_t)__builtin_ctzll(fm) : n;
     }
-    ctl->commit_n = commit;
+    __syncthreads();
+    const uint32_t commit = s_commit;
+    // a match of a kept pair that touches a match of a dropped pair keeps its plain neighbour
+    for (uint32_t i = tid; i < (uint32_t)(kBatchMax * kBatchMax); i += blockDim.x) {
+        const uint32_t r = i / kBatchMax, q = i % kBatchMax;
+        if (r >= n || q >= n) continue;
+        const uint32_t w = hdr_adj[i];
+        if (!w) continue;
+        if (r >= commit && q < commit) {            // dropped match r directly before kept match q
+            atomicAdd(&LR[lr_idx(bs->key[r] & 0xFFFFu, q, 0)], w);
+            hdr_adj[i] = 0;
+        } else if (r < commit && q >= commit) {     // kept match r directly before dropped match q
+            atomicAdd(&LR[lr_idx(bs->key[q] >> 16, r, 1)], w);
+            hdr_adj[i] = 0;
+        }
+    }
+    if (tid >= commit && tid < n) {
+        const uint32_t e = bs->eidx[tid];
+        atomicMax(&t.bmax[e >> kBlockShift], bs->packed[tid]);
+        atomicMax(&t.smax[e >> (2 * kBlockShift)], bs->packed[tid]);
+    }
+    if (tid == 0) ctl->commit_n = commit;
 }
 
 // table updates of the surviving prefix; clears every delta of the batch
@@ -1568,7 +1580,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *__re
                 ++my_rm;
             } else if (n1 != kHole && pair_test(lut, self, n1 & idmask)) {
                 is_a = true;
-                s[j] = (X0 + (uint32_t)lut_index(lut, n_keys, self, n1 & idmask)) | (n1 & endbit);
+                s[j] = (X0 + (uint32_t)lut_index(lut, self, n1 & idmask)) | (n1 & endbit);
                 changed = true;
             }
             a1 = is_a;
@@ -1921,7 +1933,7 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     if (blocks > 2048) blocks = 2048;
     if (blocks < 2) blocks = 2;
     hipLaunchKernelGGL(k_delta_max, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, LR, bs, ctl);
-    hipLaunchKernelGGL(k_validate, dim3(1), dim3(64), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
+    hipLaunchKernelGGL(k_validate, dim3(1), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     hipLaunchKernelGGL(k_apply_batch, dim3(blocks), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
 }
 

@@ -86,7 +86,7 @@ struct DevCtl {
 
 // A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
 // stream (see k_select_batch).  Per batch scratch, device memory:
-constexpr int kBatchMax = 16;
+constexpr int kBatchMax = 64;
 struct BatchState {
     uint32_t key[kBatchMax];      // (first << 16) | second
     uint32_t eidx[kBatchMax];     // entry index in the pair table
