@@ -811,7 +811,7 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
 }
 
 template <bool CHUNKED, int DIAG>
-__global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ tok,
+__global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_t *tok1,
                                                          const TileSum *__restrict__ sin,
                                                          TileSum *__restrict__ sout, uint32_t n_tiles,
                                                          uint32_t *__restrict__ chg,
@@ -826,11 +826,13 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *__restrict__ 
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     if (tile >= n_tiles) return;
 
-    if (seq) {      // inside a batch sequence: the merge index lives on the device
+    uint16_t *tok = tok0;
+    if (seq) {      // inside a batch sequence: the merge index and the current buffer live on the device
         if (ctl->batch_n != 1) return;
         const uint32_t k = ctl->k_done;
         best_ptr += k;
         X = 256u + k;
+        if (ctl->cur) tok = tok1;
     }
     const unsigned long long best = *best_ptr;
     if ((best >> 32) == 0) return;   // count 0 (or no pair at all): nothing can match
@@ -1015,7 +1017,7 @@ struct BatchLut {
 };
 
 __device__ __forceinline__ uint32_t pair_hash(uint32_t first, uint32_t second) {
-    return (__umul24(first, 40503u) + second) & (kBuckets - 1u);
+    return (__umul24(second, 2531u) + first) & (kBuckets - 1u);      // one v_mad_u32_u24
 }
 
 __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys) {
@@ -1053,7 +1055,7 @@ __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, ui
 
 __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevCtl *ctl, BatchState *bs,
                                                                unsigned long long *best, uint32_t n_target,
-                                                               uint32_t max_batch) {
+                                                               uint32_t max_batch, uint32_t fused_min) {
     __shared__ Top2 sh[kHierThreads / kWave];
     __shared__ uint32_t s_keys[kBatchMax];
     const uint32_t tid = threadIdx.x;
@@ -1061,7 +1063,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
     const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
     const uint32_t n = ctl->n_entries < t.ecap ? ctl->n_entries : t.ecap;
     __syncthreads();
-    if (tid == 0) { ctl->batch_n = 0; ctl->commit_n = 0; }
+    if (tid == 0) { ctl->batch_n = 0; ctl->commit_n = 0; ctl->fused = 0; }
     if (k0 >= k_limit || n == 0) return;
     uint32_t limit = k_limit - k0;
     if (limit > max_batch) limit = max_batch;
@@ -1174,6 +1176,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
     if (tid == 0) {
         ctl->batch_n = accepted;
         ctl->commit_n = accepted;      // k_validate lowers it for multi-pair batches
+        ctl->fused = accepted >= 2 && accepted >= fused_min ? 1u : 0u;   // large batch: k_fused_batch
         if (accepted) ctl->n_batches += 1;
     }
 }
@@ -1243,6 +1246,13 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     const Neigh nb = tile_neighbours(s, h);
+    if (DIAG == 4) {
+        asm volatile("" :: "v"(nb.p1_in), "v"(nb.p2_in));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(nb.n1v[j]), "v"(nb.n2v[j]));
+        if (lane_id() == 0) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
+        return;
+    }
     bool any = false;
     uint32_t p1 = nb.p1_in, p2 = nb.p2_in;
     bool a1 = false;       // p1 started a match (so the current token is its second element)
@@ -1282,7 +1292,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
 }
 
 template <bool CHUNKED, int DIAG = 0>
-__global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__restrict__ tok,
+__global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *tok0, const uint16_t *tok1,
                                                               const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                               uint32_t *__restrict__ chg, const BatchState *bs,
                                                               uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
@@ -1294,7 +1304,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
     const uint32_t n_keys = ctl->batch_n;
-    if (n_keys < 2) return;
+    if (n_keys < 2 || ctl->fused) return;
+    const uint16_t *tok = ctl->cur ? tok1 : tok0;
     lut_build(lut, bs, n_keys);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     if (tile >= n_tiles) return;
@@ -1354,6 +1365,211 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *__
         t0 = t1; t1 = t2; t2 = t3;
         v1 = v2; v2 = v3;
     }
+}
+
+// ---- the fused pass of a large batch ----------------------------------------------------
+// With several dozen pairs in a batch most tiles hold a match, so the separate
+// "count, validate, rewrite the marked tiles" scheme reads the stream nearly
+// twice.  The fused pass reads every tile once from the current token buffer,
+// counts the deltas AND writes the merged tile to the OTHER buffer (every tile,
+// so that buffer is complete); new summaries of the changed tiles go to the
+// side array as usual.  If validation keeps the whole batch, k_seq_finish just
+// flips ctl->cur and nothing else touches the stream; if it drops a suffix,
+// the other buffer is simply abandoned and k_rewrite_marked applies the
+// surviving prefix to the current buffer, exactly as after k_scan_batch.
+//
+// Matches of a batch cannot overlap, so "slot j starts a match" (mask A) is one
+// exact table test per slot, and "slot j is the second token of a match" (mask
+// B) is A moved to the next live slot.  That move, inside a lane and from lane
+// to lane over empty lanes, is a carry chain: ((A << 1 | carry_in) + holes) &
+// live.  Everything else (pair index, neighbours, deltas) is only done where a
+// match is.
+
+template <bool CHUNKED>
+__device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint32_t cj[8], uint32_t Am,
+                                                 unsigned long long m_live, uint32_t c_init, const Halo h,
+                                                 uint32_t tile_first, uint32_t old_x, uint32_t old_y,
+                                                 uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
+                                                 TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
+                                                 uint32_t &wave_rm) {
+    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    const uint32_t lane = lane_id();
+    const unsigned long long lane_bit = 1ull << lane;
+    uint32_t Lm = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Lm |= (s[j] != kHole ? 1u : 0u) << j;
+    const uint32_t Hm = Lm ^ 0xFFu;
+    const unsigned long long E = ~m_live;
+
+    // carry "the last live token before this lane starts a match" over empty lanes
+    const bool lastA = Am > (Lm & ~Am);
+    const unsigned long long G = __ballot(lastA);
+    const bool tcin = pair_test(lut, h.p1, tile_first & idmask);          // uniform
+    const unsigned long long CIN = (((G << 1) | (tcin ? 1ull : 0ull)) + E) & m_live;
+    const uint32_t cin = (CIN & lane_bit) != 0ull ? 1u : 0u;
+    const uint32_t Bm = (((Am << 1) | cin) + Hm) & Lm;
+    // the same for "the last live token before this lane ends a match"
+    const bool lastB = Bm > (Lm & ~Bm);
+    const unsigned long long GB = __ballot(lastB);
+    const bool tbin = h.p2 != kHole && pair_test(lut, h.p2, h.p1 & idmask);   // uniform
+    const unsigned long long BIN = (((GB << 1) | (tbin ? 1ull : 0ull)) + E) & m_live;
+    const uint32_t bin = (BIN & lane_bit) != 0ull ? 1u : 0u;
+    const uint32_t touch = Am & ((((Bm << 1) | bin) + Hm) & Lm);     // starts a match right after another one
+
+    const unsigned long long ab = __ballot((Am | Bm) != 0u);
+    if (ab == 0ull) return pack8(s);
+
+    // last live token of every lane and, where it starts a match, the index of that match
+    uint32_t ll = kHole;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ll = s[j] != kHole ? s[j] : ll;
+    uint32_t lastj = 0;
+    if (lastA) lastj = (uint32_t)lut_index(lut, ll, c_init & idmask);
+    const unsigned long long lo = m_live & (lane_bit - 1ull);
+    const uint32_t src = lo ? 63u - (uint32_t)__builtin_clzll(lo) : lane;
+    const uint32_t got = __shfl(ll | (lastj << 16), src, kWave);
+    uint32_t p1 = lo ? (got & 0xFFFFu) : h.p1;
+    uint32_t pj = lo ? (got >> 16) : (tcin ? (uint32_t)lut_index(lut, h.p1, tile_first & idmask) : 0u);
+    uint32_t pjb = 0;
+    // rare: the token before this lane ends a match and this lane's first live token starts one
+    if (__ballot(bin != 0u && (Am & Lm & (0u - Lm)) != 0u) != 0ull) {
+        const Neigh nb = tile_neighbours(s, h);
+        if (bin) pjb = (uint32_t)lut_index(lut, nb.p2_in, p1 & idmask);
+    }
+
+    uint32_t out[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t self = s[j];
+        uint32_t nv = self;
+        if ((Am >> j) & 1u) {                             // first token of a match
+            const uint32_t ja = (uint32_t)lut_index(lut, self, cj[j] & idmask);
+            nv = (X0 + ja) | (cj[j] & endbit);
+            if (p1 != kHole && !(p1 & endbit)) {
+                if ((touch >> j) & 1u) {                  // ... (a', b') (a, b): (b', a) -> (X', X)
+                    atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
+                    atomicSub(&LR[lr_idx(self, pjb, 1)], 1u);   // takes back the R count of (a', b') below
+                } else {
+                    atomicAdd(&LR[lr_idx(p1, ja, 0)], 1u);
+                }
+            }
+            pj = ja;
+        } else if ((Bm >> j) & 1u) {                      // second token of a match
+            nv = kHole;
+            if (!(self & endbit) && cj[j] != kHole) atomicAdd(&LR[lr_idx(cj[j] & idmask, pj, 1)], 1u);
+            pjb = pj;
+        }
+        p1 = self != kHole ? self : p1;
+        out[j] = nv;
+    }
+
+    const uint32_t removed = rfl(wave_sum(__popc(Bm)));
+    wave_rm += removed;
+    // New summary.  Heads and tails only change when a match touches the first two or the
+    // last two live tokens; a trailing run of equal tokens (tail_run > 1) is recounted.
+    const unsigned long long b1 = m_live & (0ull - m_live), m2 = m_live ^ b1;
+    const unsigned long long lowmask = m2 ? (((m2 & (0ull - m2)) << 1) - 1ull) : ~0ull;
+    const uint32_t h1 = 63u - (uint32_t)__builtin_clzll(m_live);
+    const unsigned long long m3 = m_live & ~(1ull << h1);
+    const unsigned long long highmask = m3 ? ~((1ull << (63u - (uint32_t)__builtin_clzll(m3))) - 1ull) : ~0ull;
+    uint4 ns;
+    if ((ab & (lowmask | highmask)) != 0ull || (old_z >> 16) != 1u) {
+        ns = wave_summary(out);
+    } else {
+        ns = make_uint4(old_x, old_y, (old_z & 0xFFFF0000u) | ((old_z & 0xFFFFu) - removed), 0u);
+    }
+    if (lane == 0) {
+        reinterpret_cast<uint4 *>(sout)[tile] = ns;
+        atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
+    }
+    return pack8(out);
+}
+
+template <bool CHUNKED>
+__global__ __launch_bounds__(kMergeThreads) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
+                                                               const TileSum *__restrict__ sin,
+                                                               TileSum *__restrict__ sout, uint32_t n_tiles,
+                                                               uint32_t *__restrict__ chg, const BatchState *bs,
+                                                               uint32_t *hdr_adj, uint32_t *LR, DevCtl *ctl,
+                                                               const RankEdge *le, const RankEdge *re) {
+    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    __shared__ BatchLut lut;
+    const uint32_t lane = lane_id();
+    const uint32_t waves_per_block = kMergeThreads / kWave;
+    const uint32_t n_waves = gridDim.x * waves_per_block;
+    const uint32_t n_keys = ctl->batch_n;
+    if (n_keys < 2 || !ctl->fused) return;
+    const uint16_t *tok = ctl->cur ? tok1 : tok0;
+    uint16_t *dst = ctl->cur ? tok0 : tok1;
+    const uint32_t X0 = 256u + ctl->k_done;
+    lut_build(lut, bs, n_keys);
+    uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
+    if (tile >= n_tiles) return;
+
+    const uint32_t last_tile = n_tiles - 1;
+    auto clamp_tile = [&](uint64_t t) { return (uint32_t)(t < n_tiles ? t : last_tile); };
+    const __amdgpu_buffer_rsrc_t sums_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
+    TileIn t0 = tile_issue(tok, sums_rsrc, tile);
+    TileIn t1 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + n_waves));
+    TileIn t2 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 2ull * n_waves));
+    bool v1 = (uint64_t)tile + n_waves < n_tiles, v2 = (uint64_t)tile + 2ull * n_waves < n_tiles;
+    const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    uint32_t wave_rm = 0;        // uniform
+    for (;;) {
+        const bool v3 = (uint64_t)tile + 3ull * n_waves < n_tiles;
+        TileIn t3 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 3ull * n_waves));
+
+        uint4 outq = t0.q;
+        const uint32_t old_x = rlane(t0.sm.x, 1), old_y = rlane(t0.sm.y, 1), old_z = rlane(t0.sm.z, 1);
+        if ((old_z & 0xFFFFu) != 0) {
+            uint32_t s[8];
+            unpack8(t0.q, s);
+            Halo h;
+            const uint32_t pw1 = rlane(t0.sm.y, 0), pw2 = rlane(t0.sm.z, 0);
+            const uint32_t nw0 = rlane(t0.sm.x, 2), nw2 = rlane(t0.sm.z, 2);
+            const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
+            if (fast) {
+                h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
+                h.n1 = nw0 & 0xFFFFu; h.n2 = nw0 >> 16;
+            } else {
+                h = halo_slow(sin, n_tiles, tile, le, re);
+            }
+            uint32_t lf = kHole;
+#pragma unroll
+            for (int j = 7; j >= 0; --j) lf = s[j] != kHole ? s[j] : lf;
+            const unsigned long long m_live = __ballot(lf != kHole);
+            const unsigned long long hi = m_live & gt_mask;
+            const uint32_t nf = __shfl(lf, hi ? (uint32_t)__builtin_ctzll(hi) : lane, kWave);
+            const uint32_t c_init = hi ? nf : h.n1;
+            uint32_t c = c_init;
+            uint32_t cj[8];
+            bool hit[8];
+#pragma unroll
+            for (int j = 7; j >= 0; --j) {
+                cj[j] = c;
+                hit[j] = pair_test(lut, s[j], c & idmask);
+                c = s[j] != kHole ? s[j] : c;
+            }
+            const bool any = hit[0] | hit[1] | hit[2] | hit[3] | hit[4] | hit[5] | hit[6] | hit[7];
+            const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
+            if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
+                uint32_t Am = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Am |= (hit[j] ? 1u : 0u) << j;
+                outq = fused_tile_full<CHUNKED>(s, cj, Am, m_live, c_init, h, tile_first, old_x, old_y, old_z, lut,
+                                                X0, tile, sout, chg, hdr_adj, LR, wave_rm);
+            }
+        }
+        reinterpret_cast<uint4 *>(dst)[(uint64_t)tile * kWave + lane] = outq;
+
+        if (!v1) break;
+        tile += n_waves;
+        t0 = t1; t1 = t2; t2 = t3;
+        v1 = v2; v2 = v3;
+    }
+    if (lane == 0 && wave_rm) atomicAdd(&ctl->rm, wave_rm);
 }
 
 // largest entry of every L_j / R_j (after the all-reduce in a multi-GPU run)
@@ -1447,7 +1663,10 @@ __global__ __launch_bounds__(256) void k_validate(PairTable t, DevCtl *ctl, Batc
         atomicMax(&t.bmax[e >> kBlockShift], bs->packed[tid]);
         atomicMax(&t.smax[e >> (2 * kBlockShift)], bs->packed[tid]);
     }
-    if (tid == 0) ctl->commit_n = commit;
+    if (tid == 0) {
+        ctl->commit_n = commit;
+        if (ctl->fused && commit < n) ctl->rm = 0;      // k_rewrite_marked recounts for the prefix
+    }
 }
 
 // table updates of the surviving prefix; clears every delta of the batch
@@ -1502,7 +1721,7 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
 // walk it with the same prefetch ring as the streaming passes.
 __global__ void k_list_marked(const uint32_t *__restrict__ chg, uint32_t n_words, uint32_t *__restrict__ list,
                               DevCtl *ctl) {
-    if (ctl->batch_n < 2) return;
+    if (ctl->batch_n < 2 || (ctl->fused && ctl->commit_n == ctl->batch_n)) return;
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bits = w < n_words ? chg[w] : 0u;
     const uint32_t cnt = __popc(bits);
@@ -1518,7 +1737,7 @@ __global__ void k_list_marked(const uint32_t *__restrict__ chg, uint32_t n_words
 }
 
 template <bool CHUNKED>
-__global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *__restrict__ tok,
+__global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *tok0, uint16_t *tok1,
                                                                   const TileSum *__restrict__ sin,
                                                                   TileSum *__restrict__ sout, uint32_t n_tiles,
                                                                   uint32_t *__restrict__ chg,
@@ -1528,7 +1747,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *__re
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     __shared__ BatchLut lut;
-    if (ctl->batch_n < 2) return;
+    if (ctl->batch_n < 2 || (ctl->fused && ctl->commit_n == ctl->batch_n)) return;
+    uint16_t *tok = ctl->cur ? tok1 : tok0;
     const uint32_t n_keys = ctl->commit_n;
     const uint32_t X0 = 256u + ctl->k_done;
     const uint32_t n_list = ctl->n_marked;
@@ -1613,6 +1833,12 @@ __global__ void k_seq_finish(DevCtl *ctl) {
         ctl->n_live -= rm;
         ctl->rm = 0;
     }
+    if (ctl->fused && ctl->batch_n >= 2) {
+        ctl->n_fused += 1;
+        if (ctl->commit_n == ctl->batch_n) ctl->cur ^= 1u;   // the fused pass's output becomes the stream
+        else ctl->n_fused_dropped += 1;
+    }
+    ctl->fused = 0;
     ctl->k_done += ctl->commit_n;
     ctl->batch_n = 0;
     ctl->commit_n = 0;
@@ -1841,7 +2067,7 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
     hipLaunchKernelGGL(k_argmax, dim3(blocks), dim3(kArgmaxThreads), 0, s, t, ctl, best);
 }
 
-void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sin, TileSum *sout, uint32_t n_tiles,
+void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileSum *sin, TileSum *sout, uint32_t n_tiles,
                   uint32_t *chg, const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *LR,
                   DevCtl *ctl, uint32_t *m_adj, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus,
                   int seq) {
@@ -1850,21 +2076,21 @@ void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sin, TileSum *sou
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_MERGE_DIAG") ? atoi(getenv("MBPE_MERGE_DIAG")) : 0;
     if (diag == 1 && !endbit) {
-        hipLaunchKernelGGL((k_merge<false, 1>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+        hipLaunchKernelGGL((k_merge<false, 1>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq);
         return;
     }
     if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_merge<false, 2>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+        hipLaunchKernelGGL((k_merge<false, 2>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq);
         return;
     }
 #endif
     if (endbit)
-        hipLaunchKernelGGL((k_merge<true, 0>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+        hipLaunchKernelGGL((k_merge<true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq);
     else
-        hipLaunchKernelGGL((k_merge<false, 0>), grid, block, 0, s, tok, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+        hipLaunchKernelGGL((k_merge<false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq);
 }
 
@@ -1890,38 +2116,59 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 }
 
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, unsigned long long *best,
-                         uint32_t n_target, uint32_t max_batch) {
-    hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch);
+                         uint32_t n_target, uint32_t max_batch, uint32_t fused_min) {
+    hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch,
+                       fused_min);
 }
 
-void launch_scan_batch(hipStream_t s, const uint16_t *tok, const TileSum *sums, uint32_t n_tiles, uint32_t *chg,
-                       const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR, const DevCtl *ctl,
-                       const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus) {
+void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
+                        uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
+                        DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
+                        int n_cus) {
+    if (!n_tiles) return;
+    const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
+    if (endbit)
+        hipLaunchKernelGGL(k_fused_batch<true>, grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj, LR,
+                           ctl, left_edge, right_edge);
+    else
+        hipLaunchKernelGGL(k_fused_batch<false>, grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj, LR,
+                           ctl, left_edge, right_edge);
+}
+
+void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1, const TileSum *sums, uint32_t n_tiles,
+                       uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
+                       const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
+                       int n_cus) {
     if (!n_tiles) return;
     const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_SCAN_DIAG") ? atoi(getenv("MBPE_SCAN_DIAG")) : 0;
     if (diag == 1 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, 1>), grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+        hipLaunchKernelGGL((k_scan_batch<false, 1>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
                            ctl, left_edge, right_edge);
         return;
     }
     if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, 2>), grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+        hipLaunchKernelGGL((k_scan_batch<false, 2>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
                            ctl, left_edge, right_edge);
         return;
     }
     if (diag == 3 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, 3>), grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+        hipLaunchKernelGGL((k_scan_batch<false, 3>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+                           ctl, left_edge, right_edge);
+        return;
+    }
+    if (diag == 4 && !endbit) {
+        hipLaunchKernelGGL((k_scan_batch<false, 4>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
                            ctl, left_edge, right_edge);
         return;
     }
 #endif
     if (endbit)
-        hipLaunchKernelGGL((k_scan_batch<true, 0>), grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+        hipLaunchKernelGGL((k_scan_batch<true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge);
     else
-        hipLaunchKernelGGL((k_scan_batch<false, 0>), grid, block, 0, s, tok, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+        hipLaunchKernelGGL((k_scan_batch<false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge);
 }
 
@@ -1937,7 +2184,7 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     hipLaunchKernelGGL(k_apply_batch, dim3(blocks), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
 }
 
-void launch_rewrite_marked(hipStream_t s, uint16_t *tok, const TileSum *sums, TileSum *side, uint32_t n_tiles,
+void launch_rewrite_marked(hipStream_t s, uint16_t *tok, uint16_t *tok1, const TileSum *sums, TileSum *side, uint32_t n_tiles,
                            uint32_t *chg, uint32_t *list, const BatchState *bs, DevCtl *ctl,
                            const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus) {
     if (!n_tiles) return;
@@ -1945,10 +2192,10 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok, const TileSum *sums, Ti
     hipLaunchKernelGGL(k_list_marked, dim3((n_words + 255) / 256), dim3(256), 0, s, chg, n_words, list, ctl);
     const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
     if (endbit)
-        hipLaunchKernelGGL(k_rewrite_marked<true>, grid, block, 0, s, tok, sums, side, n_tiles, chg, list, bs, ctl,
+        hipLaunchKernelGGL(k_rewrite_marked<true>, grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
                            left_edge, right_edge);
     else
-        hipLaunchKernelGGL(k_rewrite_marked<false>, grid, block, 0, s, tok, sums, side, n_tiles, chg, list, bs, ctl,
+        hipLaunchKernelGGL(k_rewrite_marked<false>, grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
                            left_edge, right_edge);
 }
 

@@ -82,6 +82,10 @@ struct DevCtl {
     uint32_t commit_n;       // how many of them survive validation
     uint32_t n_batches;      // batches that did work (statistics)
     uint32_t n_marked;       // tiles in the rewrite list of the current batch
+    uint32_t cur;            // which of the two token buffers holds the stream (batch sequences)
+    uint32_t fused;          // the current batch is large enough for the fused pass (k_fused_batch)
+    uint32_t n_fused;        // fused passes run / of them abandoned by validation (statistics)
+    uint32_t n_fused_dropped;
 };
 
 // A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
@@ -141,12 +145,13 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 
 // one merge pass over the stream, in place; new summaries of changed tiles go
 // to `side`, their bits are set in `chg` (launch_apply folds them into sums)
-void launch_merge(hipStream_t s, uint16_t *tok, const TileSum *sums, TileSum *side,
+void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileSum *sums, TileSum *side,
                   uint32_t n_tiles, uint32_t *chg, const unsigned long long *best, uint32_t new_id,
                   uint32_t endbit, uint32_t *LR, DevCtl *ctl, uint32_t *m_adj /* [m, adj] accumulators */,
                   const RankEdge *left_edge, const RankEdge *right_edge, int n_cus, int seq);
 // seq != 0: the kernel runs inside a batch sequence: it reads the merge index
-// from ctl->k_done and returns at once unless the selected batch has one pair
+// from ctl->k_done and returns at once unless the selected batch has one pair;
+// tok / tok_other are then token buffers 0 / 1 and ctl->cur picks the live one
 
 // fold the merge's count deltas (L, R, m, adj) into the pair table
 // (L[x] = LR[2x], R[y] = LR[2y+1])
@@ -159,14 +164,21 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 
 // ---- batched merges (see kernels.hip "batched merges") ----
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, unsigned long long *best,
-                         uint32_t n_target, uint32_t max_batch);
-void launch_scan_batch(hipStream_t s, const uint16_t *tok, const TileSum *sums, uint32_t n_tiles, uint32_t *chg,
-                       const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR, const DevCtl *ctl,
-                       const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus);
+                         uint32_t n_target, uint32_t max_batch, uint32_t fused_min);
+// small batch: count the deltas and mark the tiles (the rewrite follows validation)
+void launch_scan_batch(hipStream_t s, const uint16_t *tok0, const uint16_t *tok1, const TileSum *sums,
+                       uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
+                       uint32_t *LR, const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge,
+                       uint32_t endbit, int n_cus);
+// large batch (ctl->fused): count the deltas and write the merged stream to the other buffer
+void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
+                        uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
+                        DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
+                        int n_cus);
 // k_delta_max + k_validate + k_apply_batch
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                          uint32_t *LR, uint32_t id_upper);
-void launch_rewrite_marked(hipStream_t s, uint16_t *tok, const TileSum *sums, TileSum *side, uint32_t n_tiles,
+void launch_rewrite_marked(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side, uint32_t n_tiles,
                            uint32_t *chg, uint32_t *list /* [n_tiles] scratch */, const BatchState *bs, DevCtl *ctl,
                            const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus);
 void launch_seq_finish(hipStream_t s, DevCtl *ctl);

@@ -178,6 +178,7 @@ struct mbpe_ctx {
     int64_t opt_hier_argmax = -1;   // -1 auto (by table size), 0 full scan, 1 hierarchical
     int64_t opt_multi_merge = 1;    // 1: several independent merges per stream pass (batch sequences)
     int64_t opt_max_batch = kBatchMax;
+    int64_t opt_fused_min = 24;     // batches of at least this many pairs take the fused pass
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
 
@@ -189,6 +190,10 @@ namespace {
 int sync_ctl(mbpe_ctx *c) {
     HIPCHK(hipMemcpyAsync(&c->h_ctl, c->ctl, sizeof(DevCtl), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->cur = (int)(c->h_ctl.cur & 1u);      // a fused pass flips the live buffer on the device
+#ifdef MBPE_DIAG
+    if (getenv("MBPE_SCAN_DIAG") || getenv("MBPE_MERGE_DIAG")) c->h_ctl.err = 0;   // timing-only kernels break the counts
+#endif
     if (c->h_ctl.err) {
         char buf[160];
         snprintf(buf, sizeof(buf), "device error flags 0x%x (1=pair table full, 2=negative count, 4=missing pair)",
@@ -291,6 +296,8 @@ int do_compact(mbpe_ctx *c) {
     patch.removed_total = 0;
     HIPCHK(hipMemcpyAsync(&c->ctl->removed_total, &patch.removed_total, sizeof(patch.removed_total),
                           hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->ctl->cur), c->cur, 1, c->stream));
+    c->h_ctl.cur = (uint32_t)c->cur;
     HIPCHK(hipStreamSynchronize(c->stream));
     c->h_ctl.removed_total = 0;
     c->stats.n_compactions++;
@@ -350,6 +357,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "hier_argmax") c->opt_hier_argmax = value;
     else if (n == "multi_merge") c->opt_multi_merge = value;
     else if (n == "max_batch") c->opt_max_batch = std::min<int64_t>(std::max<int64_t>(1, value), kBatchMax);
+    else if (n == "fused_min") c->opt_fused_min = std::max<int64_t>(2, value);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
 }
@@ -571,7 +579,7 @@ static void step_local(mbpe_ctx *c, int ev_slot) {
     const uint32_t X = 256 + c->k;
     const bool multi = is_multi(c);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
-    launch_merge(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best + c->k, X, endbit, c->LR,
+    launch_merge(c->stream, c->tok[c->cur], c->tok[1 - c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best + c->k, X, endbit, c->LR,
                  c->ctl, &c->ctl->m, multi ? c->d_left : nullptr, multi ? c->d_right : nullptr, c->n_cus, 0);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
     if (multi) {
@@ -607,12 +615,16 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     const uint32_t endbit = c->chunked ? kEndBit : 0;
     const bool multi = is_multi(c);
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
-    launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->best, c->n_target, (uint32_t)c->opt_max_batch);
+    launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->best, c->n_target, (uint32_t)c->opt_max_batch,
+                        (uint32_t)c->opt_fused_min);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
-    launch_merge(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
+    // (the live token buffer is ctl->cur: a fused pass flips it without the host knowing)
+    launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
                  multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1);
-    launch_scan_batch(c->stream, c->tok[c->cur], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
+    launch_scan_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
                       c->ctl, le, re, endbit, c->n_cus);
+    launch_fused_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->bs, c->hdr_adj, c->LR,
+                       c->ctl, le, re, endbit, c->n_cus);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
 }
 
@@ -625,7 +637,7 @@ static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge excha
     launch_batch_tables(c->stream, c->tab, c->ctl, c->bs, c->hdr_m, c->hdr_adj, c->LR, id_upper);
     launch_apply(c->stream, c->tab, c->ctl, c->best, id_upper, c->LR, multi ? c->xb : nullptr, c->sums, c->side,
                  c->chg, c->n_tiles, 1);
-    launch_rewrite_marked(c->stream, c->tok[c->cur], c->sums, c->side, c->n_tiles, c->chg, c->tile_list, c->bs, c->ctl, le, re,
+    launch_rewrite_marked(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->tile_list, c->bs, c->ctl, le, re,
                           endbit, c->n_cus);
     launch_patch_sums(c->stream, c->best, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 1);
     launch_seq_finish(c->stream, c->ctl);

@@ -25,6 +25,18 @@ def hip():
     return _hip
 
 
+FUSED_MIN = 24
+
+
+@pytest.fixture(params=[2, 1000], autouse=True, ids=["fused", "scan_rewrite"])
+def _both_batch_paths(request):
+    """Every test runs with the fused pass forced on (k_fused_batch) and forced off."""
+    global FUSED_MIN
+    FUSED_MIN = request.param
+    yield
+    FUSED_MIN = 24
+
+
 def _allreduce(trainers):
     bufs = [t.exchange_buffer() for t in trainers]
     n = bufs[0][1]
@@ -47,6 +59,7 @@ def _train_sharded(data, cuts, vocab, chunk_off=None):
         for r, t in enumerate(trainers):
             lo, hi = bounds[r], bounds[r + 1]
             t.comm_init_external(r, R)
+            t.set_option("fused_min", FUSED_MIN)
             off = None
             if chunk_off is not None:
                 sel = chunk_off[(chunk_off >= lo) & (chunk_off <= hi)]
@@ -141,6 +154,7 @@ def test_rccl_single_rank_communicator():
     with mbpe.Trainer(0) as t:
         t.comm_init(mbpe.comm_unique_id(), 0, 1)
         t.set_option("force_exchange", 1)
+        t.set_option("fused_min", FUSED_MIN)
         t.load_corpus(np.frombuffer(data, dtype=np.uint8))
         assert t.train_begin(256 + 80) == mbpe.OK
         assert t.train_steps(80) == 80

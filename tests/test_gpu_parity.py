@@ -116,6 +116,14 @@ def test_train_tiny_inputs(tr, data, vocab):
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
+DEFAULTS = {"compact_den": 8, "batch": 64, "multi_merge": 1, "max_batch": 64, "fused_min": 24, "hier_argmax": -1}
+
+
+def _defaults(tr):
+    for k, v in DEFAULTS.items():
+        tr.set_option(k, v)
+
+
 def _step_parity(tr, data, off, vocab, stride=1, **opts):
     """After every `stride` merges (1 = every step; larger values let several independent
     merges share one stream pass): chosen pairs, counts, live stream, chunk ends, pair table."""
@@ -159,8 +167,7 @@ def _step_parity(tr, data, off, vocab, stride=1, **opts):
             assert got_tab == want_tab, "pair table differs at step %d" % i
             i += 1
     finally:
-        tr.set_option("compact_den", 8)
-        tr.set_option("batch", 64)
+        _defaults(tr)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -271,36 +278,65 @@ def test_hier_argmax_text_zero_counts(tr):
         tr.set_option("hier_argmax", -1)
 
 
+# fused_min 2: every multi-pair batch takes the fused pass (k_fused_batch, output in the other
+# token buffer); 1000: never (k_scan_batch + k_rewrite_marked)
+@pytest.mark.parametrize("fused_min", [2, 1000])
 @pytest.mark.parametrize("seed", range(8))
-def test_batched_merges_parity_random_bytes(tr, seed):
+def test_batched_merges_parity_random_bytes(tr, seed, fused_min):
     # several independent merges per stream pass: compare stream + table at random strides
     rng = np.random.default_rng(500 + seed)
     n = int(rng.integers(2000, 60000))
     data = rng.integers(0, int(rng.choice([8, 40, 256])), size=n, dtype=np.uint8)
     data[0] = max(int(data[0]), 1)
-    _step_parity(tr, data, None, 256 + 120, stride=int(rng.choice([3, 7, 16, 40])),
-                 compact_den=int(rng.choice([0, 3, 8, 50])))
+    _step_parity(tr, data, None, 256 + 120, stride=int(rng.choice([3, 7, 16, 40, 100])),
+                 compact_den=int(rng.choice([0, 3, 8, 50])), fused_min=fused_min)
 
 
+@pytest.mark.parametrize("fused_min", [2, 1000])
 @pytest.mark.parametrize("seed", range(4))
-def test_batched_merges_parity_chunked_text(tr, seed):
+def test_batched_merges_parity_chunked_text(tr, seed, fused_min):
     data = read_data("taylorswift.txt")[seed * 20000:seed * 20000 + 40000]
     off = mbpe.presplit(O.GPT4_SPLIT_PATTERN if seed % 2 else O.GPT2_SPLIT_PATTERN, data)
-    _step_parity(tr, data, off, 256 + 150, stride=25)
+    _step_parity(tr, data, off, 256 + 150, stride=25, fused_min=fused_min)
+
+
+@pytest.mark.parametrize("fused_min", [2, 1000])
+def test_batched_parity_sparse_stream(tr, fused_min):
+    # few distinct tokens and no compaction: long hole runs, empty lanes and tiles, matches that
+    # straddle lanes and tiles, touching matches ("abab")
+    rng = np.random.default_rng(9)
+    data = np.frombuffer(b"abcdabab" * 3000 + bytes(rng.integers(97, 103, size=30000, dtype=np.uint8)),
+                         dtype=np.uint8)
+    _step_parity(tr, data, None, 256 + 200, stride=64, compact_den=0, fused_min=fused_min)
 
 
 def test_batched_vs_single_merge_mode(tr):
     data = O.splitmix64_bytes(77, 1 << 19)
     want_m, want_c = O.train(data, 256 + 400)
-    for mode, mb in ((0, 16), (1, 16), (1, 2), (1, 5)):
+    for mode, mb, fm in ((0, 16, 24), (1, 16, 24), (1, 64, 2), (1, 64, 1000), (1, 2, 2), (1, 5, 1000)):
         tr.set_option("multi_merge", mode)
         tr.set_option("max_batch", mb)
+        tr.set_option("fused_min", fm)
         try:
             m, c, st = tr.train_lexical(data, 256 + 400)
         finally:
-            tr.set_option("multi_merge", 1)
-            tr.set_option("max_batch", 16)
-        assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist(), (mode, mb)
+            _defaults(tr)
+        assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist(), (mode, mb, fm)
+
+
+@pytest.mark.parametrize("name", LEXICAL_GOLDENS)
+def test_train_golden_fused_pass(tr, name):
+    meta = INDEX[name]
+    data = _input(meta["input"])
+    enc = meta["encoder"]
+    off = None if enc == "basic" else mbpe.presplit(O.PATTERNS[enc], data)
+    tr.set_option("fused_min", 2)
+    try:
+        merges, counts, stats = tr.train_lexical(data, meta["vocab"], off)
+    finally:
+        _defaults(tr)
+    assert O.model_bytes(O.PATTERNS[enc], merges) == read_golden(name + ".model")
+    assert stats["n_live"] == meta["final_len"]
 
 
 def test_large_corpus_properties(tr):
