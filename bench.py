@@ -239,6 +239,9 @@ def main():
             "begin_ms": begin_stats["ms_begin"],
             "stream": {"slots": s1["n_slots"], "live": s1["n_live"], "compactions": s1["n_compactions"],
                        "pairs": s1["n_pairs"]},
+            "batches": {k: s1[k] for k in ("n_batches", "n_fused", "n_fused_dropped", "cut_conflict", "cut_bucket",
+                                           "cut_single", "cut_full", "n_validation_drops", "ms_grow_table", "ms_compact",
+                                           "n_table_grows", "ms_steps")},
             "first_counts": [int(c) for c in counts[:3]],
         }
         if not args.no_cpu_baseline and world == 1:

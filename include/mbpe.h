@@ -71,6 +71,16 @@ typedef struct {
     uint32_t merge_launches;   /* merge-kernel launches timed ("time_kernels" option) */
     float    ms_merge_kernel;  /* summed duration of those launches */
     uint32_t n_batches;        /* stream passes that merged something (several merges can share one) */
+    uint32_t n_fused;          /* of them: fused passes (large batches, merged stream written to the other buffer) */
+    uint32_t n_fused_dropped;  /* fused passes whose output was abandoned because validation kept only a prefix */
+    uint32_t cut_conflict;     /* batches ended by a pair that depends on an earlier pair of the batch */
+    uint32_t cut_bucket;       /* ... by a full lookup bucket */
+    uint32_t cut_single;       /* ... by a (t,t) or zero-count pair (merged alone) */
+    uint32_t cut_full;         /* batches that reached the size limit */
+    uint32_t n_validation_drops; /* pairs selected but not merged in that pass (validation) */
+    float    ms_grow_table;    /* host wall time spent growing the pair table (allocation + rehash) */
+    float    ms_compact;       /* host wall time spent compacting the stream */
+    uint32_t n_table_grows;
 } mbpe_stats;
 
 MBPE_API const char *mbpe_last_error(void);

@@ -98,7 +98,46 @@ __device__ __forceinline__ uint32_t hash_key(uint32_t k) {
 // insert it with count = delta.  Within one kernel no two threads ever insert
 // the same key (see k_apply / k_table_init), so a found key always has its
 // entry index published by an earlier kernel.
+__device__ __forceinline__ uint32_t dense_index(const PairTable &t, uint32_t key) {
+    return ((key >> 16) << t.vshift) | (key & 0xFFFFu);
+}
+__device__ __forceinline__ uint32_t dense_key(const PairTable &t, uint32_t e) {
+    return ((e >> t.vshift) << 16) | (e & ((1u << t.vshift) - 1u));
+}
+
+// entries the argmax has to look at
+__device__ __forceinline__ uint32_t table_size(const PairTable &t, const DevCtl *ctl) {
+    if (t.cells) return t.ecap;
+    return ctl->n_entries < t.ecap ? ctl->n_entries : t.ecap;
+}
+
+// packed (count, ~key) of entry e, 0 for a cell whose pair was never inserted
+__device__ __forceinline__ unsigned long long entry_packed(const PairTable &t, uint32_t e) {
+    if (t.cells) {
+        const uint32_t v = t.cells[e];
+        return (v & kPresent) ? pack_best((int32_t)(v & ~kPresent), dense_key(t, e)) : 0ull;
+    }
+    const int32_t c = t.ecnt[e];
+    return pack_best(c < 0 ? 0 : c, t.ekey[e]);
+}
+
 __device__ void table_add(const PairTable &t, DevCtl *ctl, uint32_t key, int32_t delta, bool may_insert) {
+    if (t.cells) {
+        const uint32_t e = dense_index(t, key);
+        if (may_insert) {
+            // a pair of a NEW token: by construction absent, and written by this thread only
+            t.cells[e] = kPresent | (uint32_t)delta;
+            atomicAdd(&ctl->n_entries, 1u);
+            const unsigned long long p = pack_best(delta, key);
+            if (p > t.bmax[e >> kBlockShift]) atomicMax(&t.bmax[e >> kBlockShift], p);
+            if (p > t.smax[e >> (2 * kBlockShift)]) atomicMax(&t.smax[e >> (2 * kBlockShift)], p);
+        } else {
+            const uint32_t old = atomicAdd(&t.cells[e], (uint32_t)delta);
+            if (!(old & kPresent)) atomicOr(&ctl->err, kErrMissingPair);
+            else if ((int32_t)(old & ~kPresent) + delta < 0) atomicOr(&ctl->err, kErrNegCount);
+        }
+        return;
+    }
     uint32_t h = hash_key(key) & t.hmask;
     for (uint32_t probe = 0; probe <= t.hmask; ++probe) {
         const unsigned long long slot = t.hslot[h];
@@ -473,11 +512,10 @@ constexpr int kArgmaxThreads = 256;
 __global__ __launch_bounds__(kArgmaxThreads) void k_argmax(PairTable t, const DevCtl *ctl,
                                                            unsigned long long *best) {
     __shared__ unsigned long long wbest[kArgmaxThreads / kWave];
-    const uint32_t n = ctl->n_entries < t.ecap ? ctl->n_entries : t.ecap;
+    const uint32_t n = table_size(t, ctl);
     unsigned long long b = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        int32_t c = t.ecnt[i];
-        unsigned long long p = pack_best(c < 0 ? 0 : c, t.ekey[i]);
+        const unsigned long long p = entry_packed(t, i);
         b = p > b ? p : b;
     }
     b = wave_max_u64(b);
@@ -541,7 +579,7 @@ __device__ Top2 block_top2(const unsigned long long v[kHierItems], uint32_t base
 __global__ __launch_bounds__(kHierThreads) void k_argmax_hier(PairTable t, const DevCtl *ctl,
                                                               unsigned long long *best) {
     __shared__ Top2 sh[kHierThreads / kWave];
-    const uint32_t n = ctl->n_entries < t.ecap ? ctl->n_entries : t.ecap;
+    const uint32_t n = table_size(t, ctl);
     if (n == 0) return;
     const uint32_t n_blocks = (n + kBlockSize - 1) >> kBlockShift;
     const uint32_t n_super = (n_blocks + kBlockSize - 1) >> kBlockShift;
@@ -574,11 +612,7 @@ __global__ __launch_bounds__(kHierThreads) void k_argmax_hier(PairTable t, const
 #pragma unroll
         for (int q = 0; q < kHierItems; ++q) {
             const uint32_t e = (B << kBlockShift) + q * kHierThreads + tid;
-            v[q] = 0;
-            if (e < n) {
-                const int32_t c = t.ecnt[e];
-                v[q] = pack_best(c < 0 ? 0 : c, t.ekey[e]);
-            }
+            v[q] = e < n ? entry_packed(t, e) : 0ull;
         }
         const Top2 te = block_top2(v, B << kBlockShift, sh);
         const unsigned long long truth = te.v1;
@@ -607,7 +641,7 @@ __global__ void k_table_init(const uint32_t *__restrict__ bp, PairTable t, DevCt
     table_add(t, ctl, key, (int32_t)c, true);
 }
 
-__global__ void k_table_rehash(PairTable t, DevCtl *ctl) {
+__global__ void k_table_rehash(PairTable t, DevCtl *ctl) {      // hashed layout only
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ctl->n_entries) return;
     uint32_t key = t.ekey[i];
@@ -1061,7 +1095,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
     const uint32_t tid = threadIdx.x;
     const uint32_t k0 = ctl->k_done;
     const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
-    const uint32_t n = ctl->n_entries < t.ecap ? ctl->n_entries : t.ecap;
+    const uint32_t n = table_size(t, ctl);
     __syncthreads();
     if (tid == 0) { ctl->batch_n = 0; ctl->commit_n = 0; ctl->fused = 0; }
     if (k0 >= k_limit || n == 0) return;
@@ -1077,16 +1111,13 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
     // Bounds and the entries of the block under inspection are cached in
     // registers (thread t owns items q * 256 + t of every level), so a round
     // costs LDS reductions plus at most one global load.
-    unsigned long long sb[kHierItems], bb[kHierItems];
-    uint32_t e_key[kHierItems];
-    int32_t e_cnt[kHierItems];
+    unsigned long long sb[kHierItems], bb[kHierItems], ev[kHierItems];
 #pragma unroll
     for (int q = 0; q < kHierItems; ++q) {
         const uint32_t i = q * kHierThreads + tid;
         sb[q] = i < n_super ? ld(&t.smax[i]) : 0ull;
         bb[q] = 0;
-        e_key[q] = kEmptyKey;
-        e_cnt[q] = 0;
+        ev[q] = 0;
     }
     uint32_t cur_S = 0xFFFFFFFFu, cur_B = 0xFFFFFFFFu;
     for (uint32_t k = 0; k < limit; ++k) {
@@ -1112,21 +1143,20 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
 #pragma unroll
                 for (int q = 0; q < kHierItems; ++q) {
                     const uint32_t e = (B << kBlockShift) + q * kHierThreads + tid;
-                    e_cnt[q] = e < n ? t.ecnt[e] : 0;
-                    e_key[q] = e < n ? t.ekey[e] : kEmptyKey;
+                    ev[q] = e < n ? entry_packed(t, e) : 0ull;
                 }
             }
             unsigned long long p[kHierItems];
 #pragma unroll
             for (int q = 0; q < kHierItems; ++q) {
-                const uint32_t e = (B << kBlockShift) + q * kHierThreads + tid;
-                p[q] = 0;
-                if (e < n) {
+                p[q] = ev[q];
+                if (p[q]) {
                     // a pair already in the batch will have count 0 once it is merged (a != b):
                     // it stays a (zero-count) candidate, SURVEY 8-S rule 4
+                    const uint32_t ekey = ~(uint32_t)p[q];
                     bool excluded = false;
-                    for (uint32_t i = 0; i < accepted; ++i) excluded |= s_keys[i] == e_key[q];
-                    p[q] = pack_best(excluded || e_cnt[q] < 0 ? 0 : e_cnt[q], e_key[q]);
+                    for (uint32_t i = 0; i < accepted; ++i) excluded |= s_keys[i] == ekey;
+                    if (excluded) p[q] = pack_best(0, ekey);
                 }
             }
             const Top2 te = block_top2(p, B << kBlockShift, sh);
@@ -1157,7 +1187,10 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
                 conflict |= (b == ai) || (a == bi);
                 same_bucket += pair_hash(ai, bi) == pair_hash(a, b);
             }
-            if (conflict || same_bucket >= 2) break;      // (a lookup bucket holds two keys)
+            if (conflict || same_bucket >= 2) {           // (a lookup bucket holds two keys)
+                if (tid == 0) { if (conflict) ctl->cut_conflict += 1; else ctl->cut_bucket += 1; }
+                break;
+            }
         }
         __syncthreads();
         if (tid == 0) {
@@ -1171,7 +1204,8 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
         }
         ++accepted;
         __syncthreads();
-        if (single) break;
+        if (single) { if (tid == 0) ctl->cut_single += 1; break; }
+        if (accepted == limit && tid == 0) ctl->cut_full += 1;
     }
     if (tid == 0) {
         ctl->batch_n = accepted;
@@ -1665,6 +1699,7 @@ __global__ __launch_bounds__(256) void k_validate(PairTable t, DevCtl *ctl, Batc
     }
     if (tid == 0) {
         ctl->commit_n = commit;
+        ctl->n_validation_drops += n - commit;
         if (ctl->fused && commit < n) ctl->rm = 0;      // k_rewrite_marked recounts for the prefix
     }
 }
@@ -1847,27 +1882,80 @@ __global__ void k_seq_finish(DevCtl *ctl) {
 
 // ---- compaction ---------------------------------------------------------------------
 
-constexpr int kScanThreads = 1024;
+// exclusive scan of n_live over the tiles in three steps: sums of 4096-tile chunks, a scan of
+// those sums by one workgroup, then the scan inside every chunk
+constexpr int kScanThreads = 256;
+constexpr int kScanPerThread = 16;
+constexpr uint32_t kScanChunk = kScanThreads * kScanPerThread;
 
-__global__ __launch_bounds__(kScanThreads) void k_tile_scan(const TileSum *__restrict__ sums, uint32_t n_tiles,
-                                                            unsigned long long *__restrict__ offsets,
-                                                            DevCtl *ctl) {
-    __shared__ unsigned long long part[kScanThreads];
-    const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
-    const uint32_t lo = threadIdx.x * per < n_tiles ? threadIdx.x * per : n_tiles;
-    const uint32_t hi = lo + per < n_tiles ? lo + per : n_tiles;
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v += shfl_xor_u64(v, d);
+    __syncthreads();
+    if (lane_id() == 0) sh[threadIdx.x / kWave] = v;
+    __syncthreads();
+    unsigned long long r = 0;
+    for (uint32_t w = 0; w < blockDim.x / kWave; ++w) r += sh[w];
+    return r;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_tile_scan_partial(const TileSum *__restrict__ sums,
+                                                                    uint32_t n_tiles,
+                                                                    unsigned long long *__restrict__ part) {
+    __shared__ unsigned long long sh[kScanThreads / kWave];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanChunk;
     unsigned long long s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += sums[i].n_live;
-    part[threadIdx.x] = s;
+    for (uint32_t i = threadIdx.x; i < kScanChunk; i += kScanThreads)
+        if (base + i < n_tiles) s += sums[base + i].n_live;
+    s = block_sum_u64(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scan_top(unsigned long long *__restrict__ part, uint32_t n_parts,
+                                                        DevCtl *ctl) {
+    __shared__ unsigned long long tot[1024];
+    const uint32_t per = (n_parts + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per < n_parts ? threadIdx.x * per : n_parts;
+    const uint32_t hi = lo + per < n_parts ? lo + per : n_parts;
+    unsigned long long s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += part[i];
+    tot[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long run = 0;
-        for (int i = 0; i < kScanThreads; ++i) { unsigned long long v = part[i]; part[i] = run; run += v; }
+        for (int i = 0; i < 1024; ++i) { const unsigned long long v = tot[i]; tot[i] = run; run += v; }
         ctl->scan_total = run;
     }
     __syncthreads();
-    unsigned long long run = part[threadIdx.x];
-    for (uint32_t i = lo; i < hi; ++i) { offsets[i] = run; run += sums[i].n_live; }
+    unsigned long long run = tot[threadIdx.x];
+    for (uint32_t i = lo; i < hi; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_tile_scan_final(const TileSum *__restrict__ sums, uint32_t n_tiles,
+                                                                  const unsigned long long *__restrict__ part,
+                                                                  unsigned long long *__restrict__ offsets) {
+    __shared__ unsigned long long th[kScanThreads];
+    const uint64_t first = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * kScanPerThread;
+    uint32_t v[kScanPerThread];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        v[i] = first + i < n_tiles ? sums[first + i].n_live : 0u;
+        s += v[i];
+    }
+    th[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = part[blockIdx.x];
+        for (int i = 0; i < kScanThreads; ++i) { const unsigned long long t = th[i]; th[i] = run; run += t; }
+    }
+    __syncthreads();
+    unsigned long long run = th[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i) {
+        if (first + i < n_tiles) offsets[first + i] = run;
+        run += v[i];
+    }
 }
 
 __global__ __launch_bounds__(kMergeThreads) void k_compact_scatter(const uint16_t *__restrict__ src,
@@ -2205,7 +2293,13 @@ void launch_seq_finish(hipStream_t s, DevCtl *ctl) {
 
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles, unsigned long long *offsets,
                       DevCtl *ctl) {
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s, sums, n_tiles, offsets, ctl);
+    // offsets has room for the chunk sums behind its n_tiles entries (tile_scan_scratch_words)
+    if (!n_tiles) return;
+    unsigned long long *part = offsets + n_tiles;
+    const uint32_t n_parts = (n_tiles + kScanChunk - 1) / kScanChunk;
+    hipLaunchKernelGGL(k_tile_scan_partial, dim3(n_parts), dim3(kScanThreads), 0, s, sums, n_tiles, part);
+    hipLaunchKernelGGL(k_tile_scan_top, dim3(1), dim3(1024), 0, s, part, n_parts, ctl);
+    hipLaunchKernelGGL(k_tile_scan_final, dim3(n_parts), dim3(kScanThreads), 0, s, sums, n_tiles, part, offsets);
 }
 
 void launch_compact_scatter(hipStream_t s, const uint16_t *src, const TileSum *sums,

@@ -55,6 +55,13 @@ constexpr unsigned long long kEmptySlot = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kBlockShift = 10;                 // argmax hierarchy: 1024 entries per block,
 constexpr uint32_t kBlockSize = 1u << kBlockShift;   // 1024 blocks per super-block
 
+// Pair table, two layouts behind the same device functions (table_add, entry_packed):
+//  * dense (cells != NULL; vocab <= 32,768): one u32 per possible pair, cell index
+//    e = (first << vshift) | second, value = kPresent | count for a pair that was ever
+//    inserted, 0 otherwise.  No hashing, no growth; inserts of a new token's pairs and
+//    updates along a row are contiguous.  ecap = number of cells = 1 << (2 * vshift).
+//  * hashed (larger vocabularies): open addressing over appended entries.
+// "Entry index" below means the cell index (dense) or the append index (hashed).
 struct PairTable {
     unsigned long long *hslot;   // [hcap] (key << 32) | entry index; kEmptySlot when free
     uint32_t *ekey;      // [ecap]
@@ -63,7 +70,10 @@ struct PairTable {
     unsigned long long *smax;   // [ecap / 1024^2 + 1] upper bound per super-block
     uint32_t  hmask;     // hcap - 1
     uint32_t  ecap;
+    uint32_t *cells;     // dense layout, else NULL
+    uint32_t  vshift;    // log2 of the row pitch of the dense layout
 };
+constexpr uint32_t kPresent = 0x80000000u;
 
 // Mutable scalars shared by the kernels of one context.
 struct DevCtl {
@@ -86,6 +96,8 @@ struct DevCtl {
     uint32_t fused;          // the current batch is large enough for the fused pass (k_fused_batch)
     uint32_t n_fused;        // fused passes run / of them abandoned by validation (statistics)
     uint32_t n_fused_dropped;
+    uint32_t cut_conflict, cut_bucket, cut_single, cut_full;   // why batches ended (statistics)
+    uint32_t n_validation_drops;
 };
 
 // A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
@@ -183,7 +195,9 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const 
                            const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus);
 void launch_seq_finish(hipStream_t s, DevCtl *ctl);
 
-// compaction: exclusive scan of n_live over tiles, then scatter
+// compaction: exclusive scan of n_live over tiles, then scatter.  `offsets` needs
+// n_tiles + tile_scan_scratch(n_tiles) entries.
+inline size_t tile_scan_scratch(uint32_t n_tiles) { return (size_t)n_tiles / 4096 + 2; }
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles,
                       unsigned long long *offsets, DevCtl *ctl);
 void launch_compact_scatter(hipStream_t s, const uint16_t *src, const TileSum *sums,

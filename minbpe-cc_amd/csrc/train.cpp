@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -179,6 +180,7 @@ struct mbpe_ctx {
     int64_t opt_multi_merge = 1;    // 1: several independent merges per stream pass (batch sequences)
     int64_t opt_max_batch = kBatchMax;
     int64_t opt_fused_min = 24;     // batches of at least this many pairs take the fused pass
+    int64_t opt_dense_table = -1;   // -1 auto / 1: dense pair table when vocab <= 32,768; 0: always hashed
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
 
@@ -208,7 +210,7 @@ void free_training(mbpe_ctx *c) {
     dfree(c->tok[0]); dfree(c->tok[1]);
     dfree(c->sums); dfree(c->side); dfree(c->chg); dfree(c->tile_list);
     dfree(c->offsets);
-    dfree(c->tab.hslot); dfree(c->tab.ekey); dfree(c->tab.ecnt);
+    dfree(c->tab.hslot); dfree(c->tab.ekey); dfree(c->tab.ecnt); dfree(c->tab.cells);
     dfree(c->tab.bmax); dfree(c->tab.smax);
     dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->xb); dfree(c->xb0);
     dfree(c->d_left); dfree(c->d_right); dfree(c->bs);
@@ -224,6 +226,30 @@ void free_corpus(mbpe_ctx *c) {
     dfree(c->d_endmask);
     c->d_text = nullptr;
     c->loaded = false;
+}
+
+// dense layout: one cell per possible pair, row pitch = vocab rounded up to a power of two
+static inline bool dense_possible(const mbpe_ctx *c) { return c->vocab_size <= 32768; }
+static inline bool use_dense(const mbpe_ctx *c) {
+    if (!dense_possible(c)) return false;
+    return c->opt_dense_table != 0;      // -1 (auto) and 1: dense whenever the vocabulary allows it
+}
+
+int alloc_table_dense(mbpe_ctx *c) {
+    uint32_t vshift = 8;
+    while ((1u << vshift) < c->vocab_size) ++vshift;
+    c->tab = {};
+    c->tab.vshift = vshift;
+    c->tab.ecap = 1u << (2 * vshift);                 // <= 2^30 cells
+    const size_t cells = (size_t)1 << (2 * vshift);
+    HIPCHK(hipMalloc(&c->tab.cells, cells * 4));
+    HIPCHK(hipMemsetAsync(c->tab.cells, 0, cells * 4, c->stream));
+    const size_t nb = (cells >> kBlockShift) + 2, ns = (cells >> (2 * kBlockShift)) + 2;
+    HIPCHK(hipMalloc(&c->tab.bmax, nb * 8));
+    HIPCHK(hipMalloc(&c->tab.smax, ns * 8));
+    HIPCHK(hipMemsetAsync(c->tab.bmax, 0, nb * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->tab.smax, 0, ns * 8, c->stream));
+    return MBPE_OK;
 }
 
 int alloc_table(mbpe_ctx *c, uint32_t ecap) {
@@ -256,9 +282,19 @@ uint64_t table_cap_limit(const mbpe_ctx *c) {
     return std::max<uint64_t>(lim, 1024);
 }
 
+struct WallTimer {
+    float *acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit WallTimer(float *a) : acc(a) {}
+    ~WallTimer() { *acc += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 int grow_table(mbpe_ctx *c, uint64_t want) {
+    if (c->tab.cells) return MBPE_OK;          // the dense layout holds every possible pair
+    WallTimer timer(&c->stats.ms_grow_table);
+    c->stats.n_table_grows++;
     uint64_t lim = table_cap_limit(c);
-    uint64_t ecap = std::min<uint64_t>(std::max<uint64_t>(want, (uint64_t)c->tab.ecap * 2), lim);
+    uint64_t ecap = std::min<uint64_t>(std::max<uint64_t>(want, (uint64_t)c->tab.ecap * 4), lim);
     if (ecap <= c->tab.ecap) return MBPE_OK;   // already at the limit: cannot overflow
     PairTable old = c->tab;
     c->tab = {};
@@ -282,6 +318,7 @@ int grow_table(mbpe_ctx *c, uint64_t want) {
 int do_compact(mbpe_ctx *c) {
     // c->h_ctl must be current
     if (!c->n_tiles) return MBPE_OK;
+    WallTimer timer(&c->stats.ms_compact);
     const int src = c->cur, dst = 1 - c->cur;
     launch_tile_scan(c->stream, c->sums, c->n_tiles, c->offsets, c->ctl);
     launch_compact_scatter(c->stream, c->tok[src], c->sums, c->offsets, c->n_tiles, c->tok[dst], c->n_cus);
@@ -358,6 +395,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "multi_merge") c->opt_multi_merge = value;
     else if (n == "max_batch") c->opt_max_batch = std::min<int64_t>(std::max<int64_t>(1, value), kBatchMax);
     else if (n == "fused_min") c->opt_fused_min = std::max<int64_t>(2, value);
+    else if (n == "dense_table") c->opt_dense_table = value;
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
 }
@@ -483,6 +521,7 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
 // large tables: walk the block bounds instead of scanning every entry ("hier_argmax": -1 auto, 0 never, 1 always)
 static inline bool use_hier(const mbpe_ctx *c) {
     if (c->opt_hier_argmax >= 0) return c->opt_hier_argmax != 0;
+    if (c->tab.cells) return c->tab.ecap > (1u << 20);
     return c->h_ctl.n_entries > (1u << 20);
 }
 
@@ -509,7 +548,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(hipMalloc(&c->chg, ((size_t)c->n_tiles / 32 + 2) * 4));
     HIPCHK(hipMalloc(&c->tile_list, ((size_t)c->n_tiles + 64) * 4));
     HIPCHK(hipMemsetAsync(c->chg, 0, ((size_t)c->n_tiles / 32 + 2) * 4, c->stream));
-    HIPCHK(hipMalloc(&c->offsets, (size_t)c->n_tiles * 8));
+    HIPCHK(hipMalloc(&c->offsets, ((size_t)c->n_tiles + tile_scan_scratch(c->n_tiles)) * 8));
     const size_t xb_words = (size_t)c->hdr_words + c->hdrb_words + 2 * (size_t)kBatchMax * vocab_size + 8;
     const size_t xb0_words = 65536 + (size_t)c->hdr_words;
     HIPCHK(hipMalloc(&c->xb, xb_words * 4));
@@ -535,9 +574,13 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     }
     HIPCHK(hipMemsetAsync(c->best, 0, ((size_t)c->n_target + 2) * 8, c->stream));
 
+    // Sized for 288 GB of HBM: one entry per 8 corpus bytes up front (12 bytes of table per entry
+    // plus 16 of hash index), so that even a corpus whose pairs never repeat rarely has to grow
+    // the table -- growing means multi-GB allocations and a rehash.
     uint64_t want = 65536 + 2 * batch_headroom(c, (uint32_t)c->opt_batch);
+    want = std::max<uint64_t>(want, n / 8);
     want = std::min<uint64_t>(want, table_cap_limit(c));
-    int rc = alloc_table(c, (uint32_t)want);
+    int rc = use_dense(c) ? alloc_table_dense(c) : alloc_table(c, (uint32_t)want);
     if (rc != MBPE_OK) return rc;
 
     HIPCHK(hipEventRecord(c->ev0, c->stream));
@@ -658,6 +701,7 @@ static uint64_t seq_headroom(const mbpe_ctx *c) {
 // sequences between two host synchronisations: bounded by the "batch" option and by
 // the table headroom they need (8M entries at most)
 static uint32_t seqs_per_sync(const mbpe_ctx *c) {
+    if (c->tab.cells) return (uint32_t)std::max<int64_t>(1, c->opt_batch);    // nothing to reserve
     uint64_t g = (8ull << 20) / seq_headroom(c);
     g = std::max<uint64_t>(1, std::min<uint64_t>(g, (uint64_t)c->opt_batch));
     return (uint32_t)g;
@@ -677,7 +721,7 @@ static int after_batch(mbpe_ctx *c) {
 }
 
 static int before_batch(mbpe_ctx *c, uint32_t batch) {
-    if ((uint64_t)c->h_ctl.n_entries + batch_headroom(c, batch) > c->tab.ecap)
+    if (!c->tab.cells && (uint64_t)c->h_ctl.n_entries + batch_headroom(c, batch) > c->tab.ecap)
         return grow_table(c, ((uint64_t)c->h_ctl.n_entries + batch_headroom(c, batch)) * 2);
     return MBPE_OK;
 }
@@ -713,7 +757,7 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
     HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->ctl->k_limit), (int)target, 1, c->stream));
     while (c->k < target && !c->exhausted) {
         const uint32_t group = seqs_per_sync(c);
-        if ((uint64_t)c->h_ctl.n_entries + seq_headroom(c) * group > c->tab.ecap) {
+        if (!c->tab.cells && (uint64_t)c->h_ctl.n_entries + seq_headroom(c) * group > c->tab.ecap) {
             int rc = grow_table(c, ((uint64_t)c->h_ctl.n_entries + seq_headroom(c) * group) * 2);
             if (rc != MBPE_OK) return rc;
         }
@@ -780,7 +824,7 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
         if (use_batches(c)) {
             HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->ctl->k_limit), (int)c->pending_target, 1,
                                      c->stream));
-            if ((uint64_t)c->h_ctl.n_entries + seq_headroom(c) > c->tab.ecap) {
+            if (!c->tab.cells && (uint64_t)c->h_ctl.n_entries + seq_headroom(c) > c->tab.ecap) {
                 int rc = grow_table(c, ((uint64_t)c->h_ctl.n_entries + seq_headroom(c)) * 2);
                 if (rc != MBPE_OK) return rc;
             }
@@ -901,7 +945,7 @@ int mbpe_comm_exchange_done(mbpe_ctx *c) {
         rc = after_batch(c);
         if (rc != MBPE_OK) return rc;
         if (c->k < c->pending_target && c->k != before) {
-            if ((uint64_t)c->h_ctl.n_entries + seq_headroom(c) > c->tab.ecap) {
+            if (!c->tab.cells && (uint64_t)c->h_ctl.n_entries + seq_headroom(c) > c->tab.ecap) {
                 rc = grow_table(c, ((uint64_t)c->h_ctl.n_entries + seq_headroom(c)) * 2);
                 if (rc != MBPE_OK) return rc;
             }
@@ -944,6 +988,13 @@ int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
     c->stats.n_merges = c->exhausted ? 0 : c->n_valid;
     c->stats.n_pairs = c->begun ? c->h_ctl.n_entries : 0;
     c->stats.n_batches = c->begun ? (use_batches(c) ? c->h_ctl.n_batches : c->k) : 0;
+    c->stats.n_fused = c->begun ? c->h_ctl.n_fused : 0;
+    c->stats.n_fused_dropped = c->begun ? c->h_ctl.n_fused_dropped : 0;
+    c->stats.cut_conflict = c->begun ? c->h_ctl.cut_conflict : 0;
+    c->stats.cut_bucket = c->begun ? c->h_ctl.cut_bucket : 0;
+    c->stats.cut_single = c->begun ? c->h_ctl.cut_single : 0;
+    c->stats.cut_full = c->begun ? c->h_ctl.cut_full : 0;
+    c->stats.n_validation_drops = c->begun ? c->h_ctl.n_validation_drops : 0;
     *out = c->stats;
     return MBPE_OK;
 }
@@ -997,6 +1048,25 @@ int mbpe_get_pairs(mbpe_ctx *c, uint32_t *first_out, uint32_t *second_out, int32
     *n_out = n;
     if (!first_out) return MBPE_OK;
     if (cap < n) { mbpe_host::set_last_error("pair arrays too small"); return MBPE_ERR_ARG; }
+    if (c->tab.cells) {
+        // dense layout: the rows of the ids that exist, one at a time (row-major = key order)
+        const uint32_t pitch = 1u << c->tab.vshift, ids = std::min<uint32_t>(256 + c->k, pitch);
+        std::vector<uint32_t> row(pitch);
+        uint64_t o = 0;
+        for (uint32_t f = 0; f < ids; ++f) {
+            HIPCHK(hipMemcpy(row.data(), c->tab.cells + (size_t)f * pitch, (size_t)ids * 4, hipMemcpyDeviceToHost));
+            for (uint32_t sec = 0; sec < ids; ++sec) {
+                if (!(row[sec] & kPresent)) continue;
+                if (o >= n) { mbpe_host::set_last_error("pair table holds more pairs than counted"); return MBPE_ERR_OVERFLOW; }
+                first_out[o] = f;
+                second_out[o] = sec;
+                if (count_out) count_out[o] = (int32_t)(row[sec] & ~kPresent);
+                ++o;
+            }
+        }
+        if (o != n) { mbpe_host::set_last_error("pair table holds fewer pairs than counted"); return MBPE_ERR_OVERFLOW; }
+        return MBPE_OK;
+    }
     std::vector<uint32_t> keys(n);
     std::vector<int32_t> cnts(n);
     if (n) {

@@ -41,6 +41,10 @@ class Stats(ctypes.Structure):
         ("n_pairs", ctypes.c_uint64), ("ms_pair_count", ctypes.c_float), ("ms_begin", ctypes.c_float),
         ("ms_steps", ctypes.c_float), ("pair_count_launches", ctypes.c_uint32), ("merge_launches", ctypes.c_uint32),
         ("ms_merge_kernel", ctypes.c_float), ("n_batches", ctypes.c_uint32),
+        ("n_fused", ctypes.c_uint32), ("n_fused_dropped", ctypes.c_uint32), ("cut_conflict", ctypes.c_uint32),
+        ("cut_bucket", ctypes.c_uint32), ("cut_single", ctypes.c_uint32), ("cut_full", ctypes.c_uint32),
+        ("n_validation_drops", ctypes.c_uint32), ("ms_grow_table", ctypes.c_float), ("ms_compact", ctypes.c_float),
+        ("n_table_grows", ctypes.c_uint32),
     ]
 
     def as_dict(self):

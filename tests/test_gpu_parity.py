@@ -116,7 +116,8 @@ def test_train_tiny_inputs(tr, data, vocab):
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
-DEFAULTS = {"compact_den": 8, "batch": 64, "multi_merge": 1, "max_batch": 64, "fused_min": 24, "hier_argmax": -1}
+DEFAULTS = {"compact_den": 8, "batch": 64, "multi_merge": 1, "max_batch": 64, "fused_min": 24, "hier_argmax": -1,
+            "dense_table": -1}
 
 
 def _defaults(tr):
@@ -240,11 +241,24 @@ def test_vocab_limits(tr):
     assert e.value.code == mbpe.ERR_VOCAB
 
 
-def test_large_vocab_many_merges(tr):
-    # vocab 4096 on 256 KiB of random bytes: table growth + thousands of steps
+@pytest.mark.parametrize("dense", [0, 1])
+def test_large_vocab_many_merges(tr, dense):
+    # vocab 4096 on 256 KiB of random bytes: table growth (hashed layout) + thousands of steps
     data = O.splitmix64_bytes(9, 1 << 18)
     want_m, want_c = O.train(data, 4096)
-    m, c, _ = tr.train_lexical(data, 4096)
+    tr.set_option("dense_table", dense)
+    try:
+        m, c, _ = tr.train_lexical(data, 4096)
+    finally:
+        _defaults(tr)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
+def test_vocab_beyond_the_dense_table(tr):
+    # vocab > 32,768: the hashed pair table is the only layout; more merges than the text has pairs
+    data = read_data("taylorswift.txt")[:30000]
+    want_m, want_c = O.train(data, 40000)
+    m, c, _ = tr.train_lexical(data, 40000)
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
@@ -280,24 +294,27 @@ def test_hier_argmax_text_zero_counts(tr):
 
 # fused_min 2: every multi-pair batch takes the fused pass (k_fused_batch, output in the other
 # token buffer); 1000: never (k_scan_batch + k_rewrite_marked)
+# dense_table 1: one cell per possible pair (vocab <= 32,768); 0: the hashed table of larger vocabularies
+@pytest.mark.parametrize("dense", [0, 1])
 @pytest.mark.parametrize("fused_min", [2, 1000])
 @pytest.mark.parametrize("seed", range(8))
-def test_batched_merges_parity_random_bytes(tr, seed, fused_min):
+def test_batched_merges_parity_random_bytes(tr, seed, fused_min, dense):
     # several independent merges per stream pass: compare stream + table at random strides
     rng = np.random.default_rng(500 + seed)
     n = int(rng.integers(2000, 60000))
     data = rng.integers(0, int(rng.choice([8, 40, 256])), size=n, dtype=np.uint8)
     data[0] = max(int(data[0]), 1)
     _step_parity(tr, data, None, 256 + 120, stride=int(rng.choice([3, 7, 16, 40, 100])),
-                 compact_den=int(rng.choice([0, 3, 8, 50])), fused_min=fused_min)
+                 compact_den=int(rng.choice([0, 3, 8, 50])), fused_min=fused_min, dense_table=dense)
 
 
+@pytest.mark.parametrize("dense", [0, 1])
 @pytest.mark.parametrize("fused_min", [2, 1000])
 @pytest.mark.parametrize("seed", range(4))
-def test_batched_merges_parity_chunked_text(tr, seed, fused_min):
+def test_batched_merges_parity_chunked_text(tr, seed, fused_min, dense):
     data = read_data("taylorswift.txt")[seed * 20000:seed * 20000 + 40000]
     off = mbpe.presplit(O.GPT4_SPLIT_PATTERN if seed % 2 else O.GPT2_SPLIT_PATTERN, data)
-    _step_parity(tr, data, off, 256 + 150, stride=25, fused_min=fused_min)
+    _step_parity(tr, data, off, 256 + 150, stride=25, fused_min=fused_min, dense_table=dense)
 
 
 @pytest.mark.parametrize("fused_min", [2, 1000])
@@ -326,11 +343,13 @@ def test_batched_vs_single_merge_mode(tr):
 
 @pytest.mark.parametrize("name", LEXICAL_GOLDENS)
 def test_train_golden_fused_pass(tr, name):
+    # (and the hashed pair table; the default run above uses the dense one)
     meta = INDEX[name]
     data = _input(meta["input"])
     enc = meta["encoder"]
     off = None if enc == "basic" else mbpe.presplit(O.PATTERNS[enc], data)
     tr.set_option("fused_min", 2)
+    tr.set_option("dense_table", 0)
     try:
         merges, counts, stats = tr.train_lexical(data, meta["vocab"], off)
     finally:
