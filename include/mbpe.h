@@ -81,6 +81,7 @@ typedef struct {
     float    ms_grow_table;    /* host wall time spent growing the pair table (allocation + rehash) */
     float    ms_compact;       /* host wall time spent compacting the stream */
     uint32_t n_table_grows;
+    uint32_t n_sel_fallback;   /* batches chosen by the bound-walking selection instead of the threshold gather */
 } mbpe_stats;
 
 MBPE_API const char *mbpe_last_error(void);

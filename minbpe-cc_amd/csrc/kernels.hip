@@ -1093,6 +1093,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
     __shared__ Top2 sh[kHierThreads / kWave];
     __shared__ uint32_t s_keys[kBatchMax];
     const uint32_t tid = threadIdx.x;
+    if (ctl->sel_ok) return;                 // k_sel_pick already chose this batch
     const uint32_t k0 = ctl->k_done;
     const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
     const uint32_t n = table_size(t, ctl);
@@ -1211,9 +1212,162 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
         ctl->batch_n = accepted;
         ctl->commit_n = accepted;      // k_validate lowers it for multi-pair batches
         ctl->fused = accepted >= 2 && accepted >= fused_min ? 1u : 0u;   // large batch: k_fused_batch
-        if (accepted) ctl->n_batches += 1;
+        if (accepted) {
+            ctl->n_batches += 1;
+            ctl->n_sel_fallback += 1;
+            // prime the threshold selection: assume the next batch spans about the same range of counts
+            const unsigned long long c_hi = bs->packed[0] >> 32, c_lo = bs->packed[accepted - 1] >> 32;
+            const unsigned long long spread = c_hi - c_lo > 0 ? c_hi - c_lo : 1;
+            ctl->sel_T = c_lo > spread ? (c_lo - spread) << 32 : 0ull;
+        }
     }
 }
+
+// ---- threshold selection ------------------------------------------------------------------
+// The bound-walking kernel above pays a few dependent block reductions per selected pair.
+// With dozens of pairs per batch it is cheaper to gather, with the whole chip, EVERY entry
+// whose packed (count, ~key) is >= a threshold T (only blocks whose bound is >= T are read, and
+// their bounds are tightened on the way), sort the few hundred survivors and take the
+// independent prefix.  Any T gives a correct batch: entries that were not gathered rank below
+// all gathered ones.  T only decides how many candidates come back; k_sel_pick adapts it, and
+// leaves the batch to k_select_batch when the list is empty or overflowed.
+
+__global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelList *sel, uint32_t n_target) {
+    const unsigned long long T = ctl->sel_T;
+    const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
+    if (T == 0ull || ctl->k_done >= k_limit) return;
+    const uint32_t n = table_size(t, ctl);
+    const uint32_t n_blocks = (n + kBlockSize - 1) >> kBlockShift;
+    const uint32_t lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave, n_waves = gridDim.x * blockDim.x / kWave;
+    for (uint64_t base = (uint64_t)wave * kWave; base < n_blocks; base += (uint64_t)n_waves * kWave) {
+        const uint32_t B = (uint32_t)base + lane;
+        const unsigned long long bound =
+            B < n_blocks ? __hip_atomic_load(&t.bmax[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        unsigned long long todo = __ballot(bound >= T);
+        while (todo) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t blk = (uint32_t)base + b;
+            unsigned long long mx = 0;
+#pragma unroll 4
+            for (uint32_t q = 0; q < kBlockSize / kWave; ++q) {
+                const uint32_t e = (blk << kBlockShift) + q * kWave + lane;
+                const unsigned long long p = e < n ? entry_packed(t, e) : 0ull;
+                mx = p > mx ? p : mx;
+                const unsigned long long hit = __ballot(p >= T && p != 0ull);
+                if (hit) {
+                    uint32_t at = 0;
+                    if (lane == 0) at = atomicAdd(&ctl->sel_n, (uint32_t)__popcll(hit));
+                    at = rfl(at) + (uint32_t)__popcll(hit & lt_mask);
+                    if (p >= T && p != 0ull && at < kSelCap) { sel->packed[at] = p; sel->eidx[at] = e; }
+                }
+            }
+            mx = wave_max_u64(mx);
+            if (lane == 0) __hip_atomic_store(&t.bmax[blk], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+constexpr int kPickThreads = 1024;
+
+__global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchState *bs, const SelList *sel,
+                                                           unsigned long long *best, uint32_t n_target,
+                                                           uint32_t max_batch, uint32_t fused_min) {
+    __shared__ unsigned long long sp[kSelCap];
+    __shared__ uint32_t si[kSelCap];
+    __shared__ uint32_t s_keys[kBatchMax];
+    __shared__ uint32_t s_acc;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k0 = ctl->k_done;
+    const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
+    const uint32_t n_l = ctl->sel_n;
+    const unsigned long long T = ctl->sel_T;
+    __syncthreads();
+    if (tid == 0) { ctl->sel_n = 0; ctl->sel_ok = 0; }
+    if (k0 >= k_limit) {                       // nothing to select: the walking kernel returns at once too
+        if (tid == 0) { ctl->batch_n = 0; ctl->commit_n = 0; ctl->fused = 0; }
+        return;
+    }
+    if (T == 0ull || n_l == 0 || n_l > kSelCap) return;     // not primed / nothing above T / overflow
+    for (uint32_t i = tid; i < kSelCap; i += kPickThreads) {
+        sp[i] = i < n_l ? sel->packed[i] : 0ull;
+        si[i] = i < n_l ? sel->eidx[i] : 0u;
+    }
+    __syncthreads();
+    // bitonic sort, descending by packed value (unique per pair: a total order)
+    for (uint32_t k = 2; k <= kSelCap; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < kSelCap; i += kPickThreads) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool desc = (i & k) == 0;
+                    const unsigned long long a = sp[i], b = sp[l];
+                    if (desc ? a < b : a > b) {
+                        sp[i] = b; sp[l] = a;
+                        const uint32_t t = si[i]; si[i] = si[l]; si[l] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    uint32_t limit = k_limit - k0;
+    if (limit > max_batch) limit = max_batch;
+    if (limit > (uint32_t)kBatchMax) limit = kBatchMax;
+    // the independent prefix (one wave; lane i remembers accepted pair i)
+    if (tid < (uint32_t)kWave) {
+        uint32_t accepted = 0;
+        uint32_t my_a = 0xFFFFFFFFu, my_b = 0xFFFFFFFFu, my_h = 0xFFFFFFFFu;
+        uint32_t cut = 0;      // 1 conflict, 2 bucket, 3 single
+        for (uint32_t k = 0; k < limit && k < n_l; ++k) {
+            const unsigned long long cand = sp[k];
+            const uint32_t count = (uint32_t)(cand >> 32), key = ~(uint32_t)cand;
+            const uint32_t a = key >> 16, b = key & 0xFFFFu, h = pair_hash(a, b);
+            const bool single = count == 0 || a == b;
+            if (k > 0) {
+                const bool mine = tid < accepted;
+                const unsigned long long conf = __ballot(mine && (b == my_a || a == my_b));
+                const uint32_t same = (uint32_t)__popcll(__ballot(mine && my_h == h));
+                if (single || conf != 0ull || same >= 2) { cut = single ? 3u : (conf ? 1u : 2u); break; }
+            }
+            if (tid == accepted) { my_a = a; my_b = b; my_h = h; }
+            if (tid == 0) {
+                bs->key[accepted] = key;
+                bs->eidx[accepted] = si[k];
+                bs->packed[accepted] = cand;
+                bs->max_l[accepted] = 0;
+                bs->max_r[accepted] = 0;
+                best[k0 + accepted] = cand;
+            }
+            ++accepted;
+            if (single) { cut = 3u; break; }
+        }
+        if (tid == 0) {
+            ctl->batch_n = accepted;
+            ctl->commit_n = accepted;
+            ctl->fused = accepted >= 2 && accepted >= fused_min ? 1u : 0u;
+            ctl->n_batches += 1;
+            ctl->sel_ok = 1;
+            if (cut == 1u) ctl->cut_conflict += 1;
+            else if (cut == 2u) ctl->cut_bucket += 1;
+            else if (cut == 3u) ctl->cut_single += 1;
+            if (cut == 0u && accepted == limit) ctl->cut_full += 1;
+            // next threshold: about 128 candidates beyond this batch, or a window twice as wide
+            // when the list ended before the batch was full
+            const uint32_t want = accepted + 128u;
+            if (n_l > want) {
+                ctl->sel_T = sp[want];          // (the full packed value: also cuts inside a run of equal counts)
+            } else {
+                const unsigned long long c_hi = sp[0] >> 32, c_lo = sp[n_l - 1] >> 32;
+                const unsigned long long spread = c_hi - c_lo > 0 ? c_hi - c_lo : 1;
+                ctl->sel_T = c_lo > spread ? (c_lo - spread) << 32 : 0ull;
+            }
+        }
+    }
+}
+
 
 // exact neighbours of every slot, two deep on both sides (shared by the scan
 // and rewrite passes of a batch)
@@ -2203,8 +2357,15 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
     hipLaunchKernelGGL(k_patch_sums, dim3(blocks), dim3(256), 0, s, best, sums, side, chg, n_words, ctl, seq);
 }
 
-void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, unsigned long long *best,
-                         uint32_t n_target, uint32_t max_batch, uint32_t fused_min) {
+void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
+                         unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
+                         int n_cus) {
+    if (sel) {
+        const int blocks = (n_cus > 0 ? n_cus : 256) * 4;
+        hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target);
+        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
+                           fused_min);
+    }
     hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch,
                        fused_min);
 }

@@ -98,11 +98,24 @@ struct DevCtl {
     uint32_t n_fused_dropped;
     uint32_t cut_conflict, cut_bucket, cut_single, cut_full;   // why batches ended (statistics)
     uint32_t n_validation_drops;
+    // ---- threshold selection (k_sel_scan / k_sel_pick) ----
+    unsigned long long sel_T;   // gather every entry with packed value >= sel_T (0: not primed)
+    uint32_t sel_n;             // entries gathered by the current scan
+    uint32_t sel_ok;            // the current batch was selected from the gathered list
+    uint32_t n_sel_fallback;    // batches selected by the bound-walking kernel instead (statistics)
+    uint32_t pad_;
 };
 
 // A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
 // stream (see k_select_batch).  Per batch scratch, device memory:
 constexpr int kBatchMax = 64;
+// candidates gathered by k_sel_scan
+constexpr uint32_t kSelCap = 2048;
+struct SelList {
+    unsigned long long packed[kSelCap];
+    uint32_t eidx[kSelCap];
+};
+
 struct BatchState {
     uint32_t key[kBatchMax];      // (first << 16) | second
     uint32_t eidx[kBatchMax];     // entry index in the pair table
@@ -175,8 +188,11 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
                        uint32_t *chg, uint32_t n_tiles, DevCtl *ctl, int seq);
 
 // ---- batched merges (see kernels.hip "batched merges") ----
-void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, unsigned long long *best,
-                         uint32_t n_target, uint32_t max_batch, uint32_t fused_min);
+// k_sel_scan + k_sel_pick (gather everything above a threshold, sort, take the independent
+// prefix), then k_select_batch (walks the argmax bounds one pair at a time) if that could not be used
+void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
+                         unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
+                         int n_cus);
 // small batch: count the deltas and mark the tiles (the rewrite follows validation)
 void launch_scan_batch(hipStream_t s, const uint16_t *tok0, const uint16_t *tok1, const TileSum *sums,
                        uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,

@@ -136,6 +136,7 @@ struct mbpe_ctx {
     TileSum *side = nullptr;     // staging for the tiles a merge pass changed
     uint32_t *chg = nullptr;     // bitmap of those tiles
     uint32_t *tile_list = nullptr;   // the same as a dense list (batch rewrite pass)
+    SelList *sel = nullptr;          // candidates of the threshold selection
     unsigned long long *offsets = nullptr;
 
     // pair table
@@ -180,6 +181,7 @@ struct mbpe_ctx {
     int64_t opt_multi_merge = 1;    // 1: several independent merges per stream pass (batch sequences)
     int64_t opt_max_batch = kBatchMax;
     int64_t opt_fused_min = 24;     // batches of at least this many pairs take the fused pass
+    int64_t opt_threshold_select = 1;   // 0: always select with the bound-walking kernel
     int64_t opt_dense_table = -1;   // -1 auto / 1: dense pair table when vocab <= 32,768; 0: always hashed
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
@@ -213,7 +215,7 @@ void free_training(mbpe_ctx *c) {
     dfree(c->tab.hslot); dfree(c->tab.ekey); dfree(c->tab.ecnt); dfree(c->tab.cells);
     dfree(c->tab.bmax); dfree(c->tab.smax);
     dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->xb); dfree(c->xb0);
-    dfree(c->d_left); dfree(c->d_right); dfree(c->bs);
+    dfree(c->d_left); dfree(c->d_right); dfree(c->bs); dfree(c->sel);
     c->LR = nullptr;
     c->pending = 0;
     c->begun = false;
@@ -396,6 +398,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "max_batch") c->opt_max_batch = std::min<int64_t>(std::max<int64_t>(1, value), kBatchMax);
     else if (n == "fused_min") c->opt_fused_min = std::max<int64_t>(2, value);
     else if (n == "dense_table") c->opt_dense_table = value;
+    else if (n == "threshold_select") c->opt_threshold_select = value != 0;
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
 }
@@ -559,6 +562,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     c->hdr_adj = c->hdr_m + kBatchMax;
     c->LR = c->xb + c->hdr_words + c->hdrb_words;
     HIPCHK(hipMalloc(&c->bs, sizeof(BatchState)));
+    HIPCHK(hipMalloc(&c->sel, sizeof(SelList)));
     HIPCHK(hipMemsetAsync(c->bs, 0, sizeof(BatchState), c->stream));
     c->k_upper = 0;
     c->bp = nullptr;   // the byte-pair table lives at the front of xb0
@@ -658,8 +662,8 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     const uint32_t endbit = c->chunked ? kEndBit : 0;
     const bool multi = is_multi(c);
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
-    launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->best, c->n_target, (uint32_t)c->opt_max_batch,
-                        (uint32_t)c->opt_fused_min);
+    launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best,
+                        c->n_target, (uint32_t)c->opt_max_batch, (uint32_t)c->opt_fused_min, c->n_cus);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     // (the live token buffer is ctl->cur: a fused pass flips it without the host knowing)
     launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
@@ -995,6 +999,7 @@ int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
     c->stats.cut_single = c->begun ? c->h_ctl.cut_single : 0;
     c->stats.cut_full = c->begun ? c->h_ctl.cut_full : 0;
     c->stats.n_validation_drops = c->begun ? c->h_ctl.n_validation_drops : 0;
+    c->stats.n_sel_fallback = c->begun ? c->h_ctl.n_sel_fallback : 0;
     *out = c->stats;
     return MBPE_OK;
 }

@@ -44,7 +44,7 @@ class Stats(ctypes.Structure):
         ("n_fused", ctypes.c_uint32), ("n_fused_dropped", ctypes.c_uint32), ("cut_conflict", ctypes.c_uint32),
         ("cut_bucket", ctypes.c_uint32), ("cut_single", ctypes.c_uint32), ("cut_full", ctypes.c_uint32),
         ("n_validation_drops", ctypes.c_uint32), ("ms_grow_table", ctypes.c_float), ("ms_compact", ctypes.c_float),
-        ("n_table_grows", ctypes.c_uint32),
+        ("n_table_grows", ctypes.c_uint32), ("n_sel_fallback", ctypes.c_uint32),
     ]
 
     def as_dict(self):

@@ -117,7 +117,7 @@ def test_train_tiny_inputs(tr, data, vocab):
 
 
 DEFAULTS = {"compact_den": 8, "batch": 64, "multi_merge": 1, "max_batch": 64, "fused_min": 24, "hier_argmax": -1,
-            "dense_table": -1}
+            "dense_table": -1, "threshold_select": 1}
 
 
 def _defaults(tr):
@@ -330,15 +330,17 @@ def test_batched_parity_sparse_stream(tr, fused_min):
 def test_batched_vs_single_merge_mode(tr):
     data = O.splitmix64_bytes(77, 1 << 19)
     want_m, want_c = O.train(data, 256 + 400)
-    for mode, mb, fm in ((0, 16, 24), (1, 16, 24), (1, 64, 2), (1, 64, 1000), (1, 2, 2), (1, 5, 1000)):
+    for mode, mb, fm, ts in ((0, 16, 24, 1), (1, 16, 24, 1), (1, 64, 2, 1), (1, 64, 1000, 0), (1, 2, 2, 0),
+                             (1, 5, 1000, 1), (1, 64, 24, 0)):
         tr.set_option("multi_merge", mode)
         tr.set_option("max_batch", mb)
         tr.set_option("fused_min", fm)
+        tr.set_option("threshold_select", ts)
         try:
             m, c, st = tr.train_lexical(data, 256 + 400)
         finally:
             _defaults(tr)
-        assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist(), (mode, mb, fm)
+        assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist(), (mode, mb, fm, ts)
 
 
 @pytest.mark.parametrize("name", LEXICAL_GOLDENS)
