@@ -1042,7 +1042,7 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 // bucket within its two keys: a candidate that would be the third key of a
 // bucket ends the batch.  0xFFFE is never a token id (MBPE_MAX_VOCAB_*), so
 // kEmptyPair can never be asked for.
-constexpr uint32_t kBuckets = 1024;
+constexpr uint32_t kBuckets = 2048;
 constexpr uint32_t kEmptyPair = 0xFFFEFFFEu;
 
 struct BatchLut {
@@ -1316,10 +1316,13 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
     uint32_t limit = k_limit - k0;
     if (limit > max_batch) limit = max_batch;
     if (limit > (uint32_t)kBatchMax) limit = kBatchMax;
-    // the independent prefix (one wave; lane i remembers accepted pair i)
+    // the independent prefix (one wave; lane i remembers accepted pairs i, i + 64, ...)
     if (tid < (uint32_t)kWave) {
+        constexpr int kPer = (kBatchMax + kWave - 1) / kWave;
         uint32_t accepted = 0;
-        uint32_t my_a = 0xFFFFFFFFu, my_b = 0xFFFFFFFFu, my_h = 0xFFFFFFFFu;
+        uint32_t my_a[kPer], my_b[kPer], my_h[kPer];
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) my_a[r] = my_b[r] = my_h[r] = 0xFFFFFFFFu;
         uint32_t cut = 0;      // 1 conflict, 2 bucket, 3 single
         for (uint32_t k = 0; k < limit && k < n_l; ++k) {
             const unsigned long long cand = sp[k];
@@ -1327,12 +1330,20 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             const uint32_t a = key >> 16, b = key & 0xFFFFu, h = pair_hash(a, b);
             const bool single = count == 0 || a == b;
             if (k > 0) {
-                const bool mine = tid < accepted;
-                const unsigned long long conf = __ballot(mine && (b == my_a || a == my_b));
-                const uint32_t same = (uint32_t)__popcll(__ballot(mine && my_h == h));
+                bool c1 = false;
+                uint32_t same_l = 0;
+#pragma unroll
+                for (int r = 0; r < kPer; ++r) {      // (unused slots hold 0xFFFFFFFF: never equal)
+                    c1 |= b == my_a[r] || a == my_b[r];
+                    same_l += my_h[r] == h ? 1u : 0u;
+                }
+                const unsigned long long conf = __ballot(c1);
+                const uint32_t same = wave_sum(same_l);
                 if (single || conf != 0ull || same >= 2) { cut = single ? 3u : (conf ? 1u : 2u); break; }
             }
-            if (tid == accepted) { my_a = a; my_b = b; my_h = h; }
+#pragma unroll
+            for (int r = 0; r < kPer; ++r)
+                if (accepted == (uint32_t)r * kWave + tid) { my_a[r] = a; my_b[r] = b; my_h[r] = h; }
             if (tid == 0) {
                 bs->key[accepted] = key;
                 bs->eidx[accepted] = si[k];
@@ -1356,7 +1367,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             if (cut == 0u && accepted == limit) ctl->cut_full += 1;
             // next threshold: about 128 candidates beyond this batch, or a window twice as wide
             // when the list ended before the batch was full
-            const uint32_t want = accepted + 128u;
+            const uint32_t want = accepted + 2u * kBatchMax;
             if (n_l > want) {
                 ctl->sel_T = sp[want];          // (the full packed value: also cuts inside a run of equal counts)
             } else {
@@ -1795,8 +1806,9 @@ __global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, con
 // dropped pairs are restored.
 __global__ __launch_bounds__(256) void k_validate(PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m,
                                                   uint32_t *hdr_adj, uint32_t *LR) {
-    static_assert(kBatchMax <= kWave, "one wave validates a batch");
+    static_assert(kBatchMax <= 256, "one workgroup of 256 threads validates a batch");
     __shared__ uint32_t s_part[256 / kWave];
+    __shared__ unsigned long long s_run[256];
     __shared__ uint32_t s_commit;
     const uint32_t tid = threadIdx.x;
     const uint32_t n = ctl->batch_n;
@@ -1808,28 +1820,27 @@ __global__ __launch_bounds__(256) void k_validate(PairTable t, DevCtl *ctl, Batc
     }
     v = wave_max_u32(v);
     if (lane_id() == 0) s_part[tid / kWave] = v;
+    if (tid == 0) s_commit = n;
     __syncthreads();
-    if (tid < (uint32_t)kWave) {
-        uint32_t max_adj = 0;
-        for (uint32_t w = 0; w < 256 / kWave; ++w) max_adj = s_part[w] > max_adj ? s_part[w] : max_adj;
-        // u_j = upper bound of the count of any pair merge j creates; pair j survives iff its
-        // count beats max(u_0 .. u_{j-1}) (ties go to the safe side)
-        unsigned long long u = 0;
-        if (tid < n) {
-            const unsigned long long l = (unsigned long long)bs->max_l[tid] + max_adj;
-            const unsigned long long r = (unsigned long long)bs->max_r[tid] + max_adj;
-            u = l > r ? l : r;
-        }
-        unsigned long long run = u;         // inclusive prefix maximum
-        for (int d = 1; d < kWave; d <<= 1) {
-            const unsigned long long o = __shfl_up(run, d, kWave);
-            if ((int)tid >= d) run = o > run ? o : run;
-        }
-        const unsigned long long before = __shfl_up(run, 1, kWave);
-        const bool fails = tid >= 1 && tid < n && (bs->packed[tid] >> 32) <= before;
-        const unsigned long long fm = __ballot(fails);
-        if (tid == 0) s_commit = fm ? (uint32_t)__builtin_ctzll(fm) : n;
+    uint32_t max_adj = 0;
+    for (uint32_t w = 0; w < 256 / kWave; ++w) max_adj = s_part[w] > max_adj ? s_part[w] : max_adj;
+    // u_j = upper bound of the count of any pair merge j creates; pair j survives iff its
+    // count beats max(u_0 .. u_{j-1}) (ties go to the safe side)
+    unsigned long long u = 0;
+    if (tid < n) {
+        const unsigned long long l = (unsigned long long)bs->max_l[tid] + max_adj;
+        const unsigned long long r = (unsigned long long)bs->max_r[tid] + max_adj;
+        u = l > r ? l : r;
     }
+    s_run[tid] = u;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {        // inclusive prefix maximum
+        const unsigned long long o = tid >= d ? s_run[tid - d] : 0ull;
+        __syncthreads();
+        if (o > s_run[tid]) s_run[tid] = o;
+        __syncthreads();
+    }
+    if (tid >= 1 && tid < n && (bs->packed[tid] >> 32) <= s_run[tid - 1]) atomicMin(&s_commit, tid);
     __syncthreads();
     const uint32_t commit = s_commit;
     // a match of a kept pair that touches a match of a dropped pair keeps its plain neighbour

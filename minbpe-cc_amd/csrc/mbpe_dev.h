@@ -108,7 +108,7 @@ struct DevCtl {
 
 // A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
 // stream (see k_select_batch).  Per batch scratch, device memory:
-constexpr int kBatchMax = 64;
+constexpr int kBatchMax = 128;
 // candidates gathered by k_sel_scan
 constexpr uint32_t kSelCap = 2048;
 struct SelList {

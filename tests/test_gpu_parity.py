@@ -116,7 +116,7 @@ def test_train_tiny_inputs(tr, data, vocab):
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
-DEFAULTS = {"compact_den": 8, "batch": 64, "multi_merge": 1, "max_batch": 64, "fused_min": 24, "hier_argmax": -1,
+DEFAULTS = {"compact_den": 8, "batch": 64, "multi_merge": 1, "max_batch": 1024, "fused_min": 24, "hier_argmax": -1,
             "dense_table": -1, "threshold_select": 1}
 
 
