@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
 // live.  Everything else (pair index, neighbours, deltas) is only done where a
 // match is.
 
-template <bool CHUNKED>
+template <bool CHUNKED, int DIAG = 0>
 __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint32_t cj[8], uint32_t Am,
                                                  unsigned long long m_live, uint32_t c_init, const Halo h,
                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
@@ -1646,7 +1646,9 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
             const uint32_t ja = (uint32_t)lut_index(lut, self, cj[j] & idmask);
             nv = (X0 + ja) | (cj[j] & endbit);
             if (p1 != kHole && !(p1 & endbit)) {
-                if ((touch >> j) & 1u) {                  // ... (a', b') (a, b): (b', a) -> (X', X)
+                if (DIAG == 2) {                          // timing-only build: no delta atomics
+                    asm volatile("" :: "v"(p1), "v"(ja), "v"(pjb));
+                } else if ((touch >> j) & 1u) {           // ... (a', b') (a, b): (b', a) -> (X', X)
                     atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
                     atomicSub(&LR[lr_idx(self, pjb, 1)], 1u);   // takes back the R count of (a', b') below
                 } else {
@@ -1656,7 +1658,10 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
             pj = ja;
         } else if ((Bm >> j) & 1u) {                      // second token of a match
             nv = kHole;
-            if (!(self & endbit) && cj[j] != kHole) atomicAdd(&LR[lr_idx(cj[j] & idmask, pj, 1)], 1u);
+            if (!(self & endbit) && cj[j] != kHole) {
+                if (DIAG == 2) asm volatile("" :: "v"(cj[j]), "v"(pj));
+                else atomicAdd(&LR[lr_idx(cj[j] & idmask, pj, 1)], 1u);
+            }
             pjb = pj;
         }
         p1 = self != kHole ? self : p1;
@@ -1665,15 +1670,19 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
 
     const uint32_t removed = rfl(wave_sum(__popc(Bm)));
     wave_rm += removed;
-    // New summary.  Heads and tails only change when a match touches the first two or the
+    // New summary.  Heads and tails only change when a match touches one of the first two or
     // last two live tokens; a trailing run of equal tokens (tail_run > 1) is recounted.
-    const unsigned long long b1 = m_live & (0ull - m_live), m2 = m_live ^ b1;
-    const unsigned long long lowmask = m2 ? (((m2 & (0ull - m2)) << 1) - 1ull) : ~0ull;
-    const uint32_t h1 = 63u - (uint32_t)__builtin_clzll(m_live);
-    const unsigned long long m3 = m_live & ~(1ull << h1);
-    const unsigned long long highmask = m3 ? ~((1ull << (63u - (uint32_t)__builtin_clzll(m3))) - 1ull) : ~0ull;
+    const uint32_t ABm = Am | Bm;
+    const uint32_t top = Lm ? 31u - (uint32_t)__builtin_clz(Lm) : 0u;
+    const uint32_t lb1 = Lm & (0u - Lm), r1 = Lm ^ lb1, lb2 = r1 & (0u - r1);
+    const uint32_t hb1 = Lm ? 1u << top : 0u, r2 = Lm ^ hb1, hb2 = r2 ? 1u << (31u - (uint32_t)__builtin_clz(r2)) : 0u;
+    const uint32_t F = (uint32_t)__builtin_ctzll(m_live), Hl = 63u - (uint32_t)__builtin_clzll(m_live);
+    const unsigned long long mF = m_live & (m_live - 1ull), mH = m_live & ~(1ull << Hl);
+    bool edge = rlane(ABm & (lb1 | lb2), F) != 0u || rlane(ABm & (hb1 | hb2), Hl) != 0u;
+    if (rlane(lb2, F) == 0u && mF) edge |= rlane(ABm & lb1, (uint32_t)__builtin_ctzll(mF)) != 0u;
+    if (rlane(hb2, Hl) == 0u && mH) edge |= rlane(ABm & hb1, 63u - (uint32_t)__builtin_clzll(mH)) != 0u;
     uint4 ns;
-    if ((ab & (lowmask | highmask)) != 0ull || (old_z >> 16) != 1u) {
+    if (edge || (old_z >> 16) != 1u) {
         ns = wave_summary(out);
     } else {
         ns = make_uint4(old_x, old_y, (old_z & 0xFFFF0000u) | ((old_z & 0xFFFFu) - removed), 0u);
@@ -1685,7 +1694,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
     return pack8(out);
 }
 
-template <bool CHUNKED>
+template <bool CHUNKED, int DIAG = 0>
 __global__ __launch_bounds__(kMergeThreads) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
                                                                const TileSum *__restrict__ sin,
                                                                TileSum *__restrict__ sout, uint32_t n_tiles,
@@ -1757,7 +1766,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_fused_batch(uint16_t *tok0, u
                 uint32_t Am = 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) Am |= (hit[j] ? 1u : 0u) << j;
-                outq = fused_tile_full<CHUNKED>(s, cj, Am, m_live, c_init, h, tile_first, old_x, old_y, old_z, lut,
+                outq = fused_tile_full<CHUNKED, DIAG>(s, cj, Am, m_live, c_init, h, tile_first, old_x, old_y, old_z, lut,
                                                 X0, tile, sout, chg, hdr_adj, LR, wave_rm);
             }
         }
@@ -2250,12 +2259,21 @@ inline int blocks_for(uint64_t n, int threads, int max_blocks) {
     return (int)b;
 }
 
+// workgroups of a kernel that fit one CU at a time (registers, LDS): the strided tile loops
+// want exactly one resident "round" of workgroups, a second partial round would idle CUs
+template <typename K>
+inline int resident_blocks(K kernel) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kMergeThreads, 0) != hipSuccess || n < 1) n = 4;
+    return n > 8 ? 8 : n;
+}
+
 // grid for the wave-per-tile kernels: enough waves to fill the chip (8 blocks
 // of 4 waves per CU), fewer when the stream is short
-inline int tile_grid(uint32_t n_tiles, int n_cus) {
+inline int tile_grid(uint32_t n_tiles, int n_cus, int blocks_per_cu = 8) {
     const uint32_t waves_per_block = kMergeThreads / kWave;
     uint64_t blocks = ((uint64_t)n_tiles + waves_per_block - 1) / waves_per_block;
-    const uint64_t cap = (uint64_t)(n_cus > 0 ? n_cus : 256) * 8;
+    const uint64_t cap = (uint64_t)(n_cus > 0 ? n_cus : 256) * blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -2386,7 +2404,16 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
                         int n_cus) {
     if (!n_tiles) return;
-    const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
+    static const int occ_c = resident_blocks(k_fused_batch<true, 0>), occ_b = resident_blocks(k_fused_batch<false, 0>);
+    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
+#ifdef MBPE_DIAG
+    const int diag = getenv("MBPE_FUSED_DIAG") ? atoi(getenv("MBPE_FUSED_DIAG")) : 0;   // (re-read: set after warm-up)
+    if (diag == 2 && !endbit) {
+        hipLaunchKernelGGL((k_fused_batch<false, 2>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs,
+                           hdr_adj, LR, ctl, left_edge, right_edge);
+        return;
+    }
+#endif
     if (endbit)
         hipLaunchKernelGGL(k_fused_batch<true>, grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj, LR,
                            ctl, left_edge, right_edge);
