@@ -86,6 +86,52 @@ __device__ __forceinline__ uint32_t lr_idx(uint32_t x, uint32_t j, uint32_t side
     return ((x * kBatchMax + j) << 1) | side;
 }
 
+// Count deltas of frequent neighbours.  In text a pair such as ("e", " ") has millions of
+// occurrences whose left neighbour is one of a handful of tokens, and a global atomicAdd on
+// one address runs at roughly 10 ns each whoever issues it.  Each workgroup therefore keeps a
+// small direct-mapped cache of LR cells in LDS: a cell that owns its slot is counted with LDS
+// atomics and written back once when the kernel ends; cells that lose the race for a slot go
+// straight to memory.  `on` (uniform) is only set for batches whose top pair is frequent
+// enough for this to matter; uniform-random corpora bypass the cache.
+constexpr uint32_t kDcSlots = 1024;
+constexpr uint32_t kDcEmpty = 0xFFFFFFFFu;
+struct DeltaCache {
+    uint32_t tag[kDcSlots];
+    uint32_t cnt[kDcSlots];
+};
+
+__device__ __forceinline__ void dc_init(DeltaCache &dc) {
+    for (uint32_t i = threadIdx.x; i < kDcSlots; i += blockDim.x) { dc.tag[i] = kDcEmpty; dc.cnt[i] = 0; }
+}
+
+__device__ __forceinline__ void dc_add(DeltaCache &dc, bool on, uint32_t *LR, uint32_t idx, uint32_t delta) {
+    if (on) {
+        const uint32_t slot = (idx * 0x9E3779B1u) >> 22;          // 10 bits
+        uint32_t t = dc.tag[slot];
+        if (t == kDcEmpty) {
+            t = atomicCAS(&dc.tag[slot], kDcEmpty, idx);
+            if (t == kDcEmpty) t = idx;
+        }
+        if (t == idx) { atomicAdd(&dc.cnt[slot], delta); return; }
+    }
+    atomicAdd(&LR[idx], delta);
+}
+
+// every thread of the workgroup, once all adds are done
+__device__ __forceinline__ void dc_flush(DeltaCache &dc, uint32_t *LR) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kDcSlots; i += blockDim.x) {
+        const uint32_t c = dc.cnt[i];
+        if (c) atomicAdd(&LR[dc.tag[i]], c);
+    }
+}
+
+// is the largest pair of the pass frequent enough for hot count cells?  (one occurrence per
+// 8192 live tokens of this shard)
+__device__ __forceinline__ bool dc_wanted(unsigned long long top_count, unsigned long long n_live) {
+    return top_count * 8192ull >= n_live;
+}
+
 __device__ __forceinline__ uint32_t hash_key(uint32_t k) {
     k *= 0x9E3779B1u;
     k ^= k >> 15;
@@ -711,7 +757,8 @@ template <bool CHUNKED>
 __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *sin, TileSum *sout, uint32_t *chg,
                                                 uint32_t n_tiles,
                                              uint32_t tile, uint32_t s[8], const Halo h, uint32_t a, uint32_t b,
-                                             uint32_t X, uint32_t *LR, const RankEdge *le,
+                                             uint32_t X, uint32_t *LR, DeltaCache &dc, bool dc_on,
+                                             const RankEdge *le,
                                              uint32_t &wave_m, uint32_t &wave_adj, uint32_t &wave_rm) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
@@ -818,14 +865,14 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
             ++my_m;
             if (p1 != kHole && !(p1 & endbit)) {
                 if (prev_adjacent) ++my_adj;
-                else atomicAdd(&LR[lr_idx(p1, 0, 0)], 1u);
+                else dc_add(dc, dc_on, LR, lr_idx(p1, 0, 0), 1u);
             }
         } else if (bmatch) {
             nv = kHole;
             ++my_rm;
             if (!(self & endbit) && n1 != kHole) {
                 const bool next_adjacent = (n1 == a) && ((n2 & idmask) == b);
-                if (!next_adjacent) atomicAdd(&LR[lr_idx(n1 & idmask, 0, 1)], 1u);
+                if (!next_adjacent) dc_add(dc, dc_on, LR, lr_idx(n1 & idmask, 0, 1), 1u);
             }
         }
         p2 = p1; p1 = self;       // neighbours are the OLD tokens
@@ -844,7 +891,7 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
     return true;
 }
 
-template <bool CHUNKED, int DIAG>
+template <bool CHUNKED, bool HOT, int DIAG>
 __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_t *tok1,
                                                          const TileSum *__restrict__ sin,
                                                          TileSum *__restrict__ sout, uint32_t n_tiles,
@@ -854,11 +901,11 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
                                                          uint32_t *m_adj, const RankEdge *le,
                                                          const RankEdge *re, int seq) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    __shared__ DeltaCache dc;
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
-    if (tile >= n_tiles) return;
 
     uint16_t *tok = tok0;
     if (seq) {      // inside a batch sequence: the merge index and the current buffer live on the device
@@ -872,8 +919,13 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
     if ((best >> 32) == 0) return;   // count 0 (or no pair at all): nothing can match
     const uint32_t key = ~(uint32_t)best;
     const uint32_t a = rfl(key >> 16), b = rfl(key & 0xFFFFu);
+    // two instantiations are launched: the one with the delta cache only works on a frequent pair
+    if (dc_wanted(best >> 32, ctl->n_live) != HOT) return;
+    constexpr bool dc_on = HOT;
+    if (dc_on) { dc_init(dc); __syncthreads(); }
 
     uint32_t wave_m = 0, wave_adj = 0, wave_rm = 0;   // lane-local partial sums, reduced once at the end
+    if (tile < n_tiles) {
 
     // three tiles in flight per wave while the current one is examined
     // (past the end the last tile is re-read: loads stay unconditional)
@@ -924,8 +976,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
             }
             bool work = __ballot(acc == 0u) != 0ull || h.p1 == a;
             if (DIAG == 2) { asm volatile("" :: "v"(acc)); work = false; }
-            if (work) merge_tile_full<CHUNKED>(tok, sin, sout, chg, n_tiles, tile, s, h, a, b, X, LR, le, wave_m, wave_adj,
-                                                   wave_rm);
+            if (work) merge_tile_full<CHUNKED>(tok, sin, sout, chg, n_tiles, tile, s, h, a, b, X, LR, dc, dc_on, le, wave_m,
+                                                   wave_adj, wave_rm);
         }
 
         if (!v1) break;
@@ -933,6 +985,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
         t0 = t1; t1 = t2; t2 = t3;
         v1 = v2; v2 = v3;
     }
+    }
+    if (dc_on) dc_flush(dc, LR);
     const uint32_t tm = wave_sum(wave_m), ta = wave_sum(wave_adj), tr = wave_sum(wave_rm);
     if (lane == 0) {
         if (tm) atomicAdd(&m_adj[0], tm);
@@ -1441,7 +1495,7 @@ __device__ __forceinline__ Neigh tile_neighbours(const uint32_t s[8], const Halo
 template <bool CHUNKED, int DIAG = 0>
 __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, const uint32_t s[8], const Halo h,
                                                const BatchLut &lut, uint32_t n_keys, uint32_t *hdr_adj,
-                                               uint32_t *LR) {
+                                               uint32_t *LR, DeltaCache &dc, bool dc_on) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     const Neigh nb = tile_neighbours(s, h);
@@ -1467,7 +1521,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
             any = true;
             if (!(self & endbit) && n1 != kHole && !pair_test(lut, n1, n2 & idmask)) {
                 const int jb = lut_index(lut, p1, self & idmask);
-                if (DIAG != 3) atomicAdd(&LR[lr_idx(n1 & idmask, (uint32_t)jb, 1)], 1u);
+                if (DIAG != 3) dc_add(dc, dc_on, LR, lr_idx(n1 & idmask, (uint32_t)jb, 1), 1u);
                 else asm volatile("" :: "v"(jb));
             }
         } else if (n1 != kHole && pair_test(lut, self, n1 & idmask)) {   // first token of a match
@@ -1479,7 +1533,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
                     const int jp = lut_index(lut, p2, p1);
                     atomicAdd(&hdr_adj[jp * kBatchMax + ja], 1u);
                 } else {
-                    if (DIAG != 3) atomicAdd(&LR[lr_idx(p1, (uint32_t)ja, 0)], 1u);
+                    if (DIAG != 3) dc_add(dc, dc_on, LR, lr_idx(p1, (uint32_t)ja, 0), 1u);
                     else asm volatile("" :: "v"(ja));
                 }
             }
@@ -1490,7 +1544,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
     if (__ballot(any) != 0ull && lane_id() == 0) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
 }
 
-template <bool CHUNKED, int DIAG = 0>
+template <bool CHUNKED, bool HOT, int DIAG = 0>
 __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *tok0, const uint16_t *tok1,
                                                               const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                               uint32_t *__restrict__ chg, const BatchState *bs,
@@ -1502,12 +1556,16 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
+    __shared__ DeltaCache dc;
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2 || ctl->fused) return;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
+    if (dc_wanted(bs->packed[0] >> 32, ctl->n_live) != HOT) return;     // (see k_merge)
+    constexpr bool dc_on = HOT;
+    if (dc_on) dc_init(dc);
     lut_build(lut, bs, n_keys);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
-    if (tile >= n_tiles) return;
+    if (tile < n_tiles) {
 
     const uint32_t last_tile = n_tiles - 1;
     auto clamp_tile = [&](uint64_t t) { return (uint32_t)(t < n_tiles ? t : last_tile); };
@@ -1557,13 +1615,15 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             bool work = __ballot(cand) != 0ull || pair_test(lut, h.p1, tile_first & idmask);
             if (DIAG == 2) { asm volatile("" :: "v"((uint32_t)cand)); work = false; }
-            if (work) scan_tile_full<CHUNKED, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR);
+            if (work) scan_tile_full<CHUNKED, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, dc, dc_on);
         }
         if (!v1) break;
         tile += n_waves;
         t0 = t1; t1 = t2; t2 = t3;
         v1 = v2; v2 = v3;
     }
+    }
+    if (dc_on) dc_flush(dc, LR);
 }
 
 // ---- the fused pass of a large batch ----------------------------------------------------
@@ -1590,7 +1650,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
-                                                 uint32_t &wave_rm) {
+                                                 DeltaCache &dc, bool dc_on, uint32_t &wave_rm) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     const uint32_t lane = lane_id();
@@ -1650,9 +1710,9 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
                     asm volatile("" :: "v"(p1), "v"(ja), "v"(pjb));
                 } else if ((touch >> j) & 1u) {           // ... (a', b') (a, b): (b', a) -> (X', X)
                     atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
-                    atomicSub(&LR[lr_idx(self, pjb, 1)], 1u);   // takes back the R count of (a', b') below
+                    dc_add(dc, dc_on, LR, lr_idx(self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b') below
                 } else {
-                    atomicAdd(&LR[lr_idx(p1, ja, 0)], 1u);
+                    dc_add(dc, dc_on, LR, lr_idx(p1, ja, 0), 1u);
                 }
             }
             pj = ja;
@@ -1660,7 +1720,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
             nv = kHole;
             if (!(self & endbit) && cj[j] != kHole) {
                 if (DIAG == 2) asm volatile("" :: "v"(cj[j]), "v"(pj));
-                else atomicAdd(&LR[lr_idx(cj[j] & idmask, pj, 1)], 1u);
+                else dc_add(dc, dc_on, LR, lr_idx(cj[j] & idmask, pj, 1), 1u);
             }
             pjb = pj;
         }
@@ -1694,7 +1754,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
     return pack8(out);
 }
 
-template <bool CHUNKED, int DIAG = 0>
+template <bool CHUNKED, bool HOT, int DIAG = 0>
 __global__ __launch_bounds__(kMergeThreads) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
                                                                const TileSum *__restrict__ sin,
                                                                TileSum *__restrict__ sout, uint32_t n_tiles,
@@ -1706,14 +1766,19 @@ __global__ __launch_bounds__(kMergeThreads) void k_fused_batch(uint16_t *tok0, u
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
+    __shared__ DeltaCache dc;
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2 || !ctl->fused) return;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     uint16_t *dst = ctl->cur ? tok0 : tok1;
     const uint32_t X0 = 256u + ctl->k_done;
+    if (dc_wanted(bs->packed[0] >> 32, ctl->n_live) != HOT) return;     // (see k_merge)
+    constexpr bool dc_on = HOT;
+    if (dc_on) dc_init(dc);
     lut_build(lut, bs, n_keys);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
-    if (tile >= n_tiles) return;
+    uint32_t wave_rm = 0;        // uniform
+    if (tile < n_tiles) {
 
     const uint32_t last_tile = n_tiles - 1;
     auto clamp_tile = [&](uint64_t t) { return (uint32_t)(t < n_tiles ? t : last_tile); };
@@ -1724,7 +1789,6 @@ __global__ __launch_bounds__(kMergeThreads) void k_fused_batch(uint16_t *tok0, u
     TileIn t2 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 2ull * n_waves));
     bool v1 = (uint64_t)tile + n_waves < n_tiles, v2 = (uint64_t)tile + 2ull * n_waves < n_tiles;
     const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
-    uint32_t wave_rm = 0;        // uniform
     for (;;) {
         const bool v3 = (uint64_t)tile + 3ull * n_waves < n_tiles;
         TileIn t3 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 3ull * n_waves));
@@ -1767,7 +1831,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_fused_batch(uint16_t *tok0, u
 #pragma unroll
                 for (int j = 0; j < 8; ++j) Am |= (hit[j] ? 1u : 0u) << j;
                 outq = fused_tile_full<CHUNKED, DIAG>(s, cj, Am, m_live, c_init, h, tile_first, old_x, old_y, old_z, lut,
-                                                X0, tile, sout, chg, hdr_adj, LR, wave_rm);
+                                                X0, tile, sout, chg, hdr_adj, LR, dc, dc_on, wave_rm);
             }
         }
         reinterpret_cast<uint4 *>(dst)[(uint64_t)tile * kWave + lane] = outq;
@@ -1777,6 +1841,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_fused_batch(uint16_t *tok0, u
         t0 = t1; t1 = t2; t2 = t3;
         v1 = v2; v2 = v3;
     }
+    }
+    if (dc_on) dc_flush(dc, LR);
     if (lane == 0 && wave_rm) atomicAdd(&ctl->rm, wave_rm);
 }
 
@@ -2347,22 +2413,28 @@ void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileS
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_MERGE_DIAG") ? atoi(getenv("MBPE_MERGE_DIAG")) : 0;
     if (diag == 1 && !endbit) {
-        hipLaunchKernelGGL((k_merge<false, 1>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+        hipLaunchKernelGGL((k_merge<false, false, 1>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq);
         return;
     }
     if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_merge<false, 2>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+        hipLaunchKernelGGL((k_merge<false, false, 2>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq);
         return;
     }
 #endif
-    if (endbit)
-        hipLaunchKernelGGL((k_merge<true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+    // (both instantiations: each returns at once unless the pair's frequency is its case)
+    if (endbit) {
+        hipLaunchKernelGGL((k_merge<true, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq);
-    else
-        hipLaunchKernelGGL((k_merge<false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+        hipLaunchKernelGGL((k_merge<true, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq);
+    } else {
+        hipLaunchKernelGGL((k_merge<false, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+                           m_adj, left_edge, right_edge, seq);
+        hipLaunchKernelGGL((k_merge<false, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+                           m_adj, left_edge, right_edge, seq);
+    }
 }
 
 void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best, uint32_t new_id,
@@ -2404,22 +2476,27 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
                         int n_cus) {
     if (!n_tiles) return;
-    static const int occ_c = resident_blocks(k_fused_batch<true, 0>), occ_b = resident_blocks(k_fused_batch<false, 0>);
+    static const int occ_c = resident_blocks(k_fused_batch<true, false, 0>), occ_b = resident_blocks(k_fused_batch<false, false, 0>);
     const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
 #ifdef MBPE_DIAG
     const int diag = getenv("MBPE_FUSED_DIAG") ? atoi(getenv("MBPE_FUSED_DIAG")) : 0;   // (re-read: set after warm-up)
     if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_fused_batch<false, 2>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs,
+        hipLaunchKernelGGL((k_fused_batch<false, false, 2>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs,
                            hdr_adj, LR, ctl, left_edge, right_edge);
         return;
     }
 #endif
-    if (endbit)
-        hipLaunchKernelGGL(k_fused_batch<true>, grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj, LR,
-                           ctl, left_edge, right_edge);
-    else
-        hipLaunchKernelGGL(k_fused_batch<false>, grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj, LR,
-                           ctl, left_edge, right_edge);
+    if (endbit) {
+        hipLaunchKernelGGL((k_fused_batch<true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge);
+        hipLaunchKernelGGL((k_fused_batch<true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge);
+    } else {
+        hipLaunchKernelGGL((k_fused_batch<false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge);
+        hipLaunchKernelGGL((k_fused_batch<false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge);
+    }
 }
 
 void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1, const TileSum *sums, uint32_t n_tiles,
@@ -2431,32 +2508,37 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_SCAN_DIAG") ? atoi(getenv("MBPE_SCAN_DIAG")) : 0;
     if (diag == 1 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, 1>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+        hipLaunchKernelGGL((k_scan_batch<false, false, 1>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
                            ctl, left_edge, right_edge);
         return;
     }
     if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, 2>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+        hipLaunchKernelGGL((k_scan_batch<false, false, 2>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
                            ctl, left_edge, right_edge);
         return;
     }
     if (diag == 3 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, 3>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+        hipLaunchKernelGGL((k_scan_batch<false, false, 3>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
                            ctl, left_edge, right_edge);
         return;
     }
     if (diag == 4 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, 4>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+        hipLaunchKernelGGL((k_scan_batch<false, false, 4>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
                            ctl, left_edge, right_edge);
         return;
     }
 #endif
-    if (endbit)
-        hipLaunchKernelGGL((k_scan_batch<true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+    if (endbit) {
+        hipLaunchKernelGGL((k_scan_batch<true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge);
-    else
-        hipLaunchKernelGGL((k_scan_batch<false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+        hipLaunchKernelGGL((k_scan_batch<true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge);
+    } else {
+        hipLaunchKernelGGL((k_scan_batch<false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge);
+        hipLaunchKernelGGL((k_scan_batch<false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge);
+    }
 }
 
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
