@@ -1141,9 +1141,23 @@ __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, ui
     return (int)(lut.bucket[h].x == (first | (second << 16)) ? ix & 0xFFFFu : ix >> 16);
 }
 
+// Which pass merges a multi-pair batch: the fused one (reads the stream once, writes all of it to
+// the other buffer) or scan + rewrite of the marked tiles (reads once, then re-reads and rewrites
+// the tiles that hold a match).  The fused pass wins once a good part of the tiles hold a match:
+// many pairs, or few but frequent ones (text).  fused_min >= 1000 turns it off.
+__device__ __forceinline__ bool want_fused(const BatchState *bs, uint32_t accepted, uint32_t fused_min,
+                                           unsigned long long n_live_all) {
+    if (accepted < 2 || fused_min >= 1000u) return false;
+    if (accepted >= fused_min) return true;
+    unsigned long long matches = 0;
+    for (uint32_t i = 0; i < accepted; ++i) matches += bs->packed[i] >> 32;
+    return matches * 2048ull >= n_live_all;        // about one tile in five holds a match
+}
+
 __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevCtl *ctl, BatchState *bs,
                                                                unsigned long long *best, uint32_t n_target,
-                                                               uint32_t max_batch, uint32_t fused_min) {
+                                                               uint32_t max_batch, uint32_t fused_min,
+                                                               uint32_t n_ranks) {
     __shared__ Top2 sh[kHierThreads / kWave];
     __shared__ uint32_t s_keys[kBatchMax];
     const uint32_t tid = threadIdx.x;
@@ -1265,7 +1279,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
     if (tid == 0) {
         ctl->batch_n = accepted;
         ctl->commit_n = accepted;      // k_validate lowers it for multi-pair batches
-        ctl->fused = accepted >= 2 && accepted >= fused_min ? 1u : 0u;   // large batch: k_fused_batch
+        ctl->fused = want_fused(bs, accepted, fused_min, ctl->n_live * n_ranks) ? 1u : 0u;
         if (accepted) {
             ctl->n_batches += 1;
             ctl->n_sel_fallback += 1;
@@ -1295,10 +1309,14 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
     const uint32_t lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave, n_waves = gridDim.x * blockDim.x / kWave;
-    for (uint64_t base = (uint64_t)wave * kWave; base < n_blocks; base += (uint64_t)n_waves * kWave) {
+    // a wave looks at g bounds at a time: 64 for a large table, fewer when there are not enough
+    // blocks to give every wave something to do
+    uint32_t g = n_blocks / n_waves;
+    g = g < 1u ? 1u : (g > (uint32_t)kWave ? (uint32_t)kWave : g);
+    for (uint64_t base = (uint64_t)wave * g; base < n_blocks; base += (uint64_t)n_waves * g) {
         const uint32_t B = (uint32_t)base + lane;
-        const unsigned long long bound =
-            B < n_blocks ? __hip_atomic_load(&t.bmax[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        const unsigned long long bound = lane < g && B < n_blocks
+            ? __hip_atomic_load(&t.bmax[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         unsigned long long todo = __ballot(bound >= T);
         while (todo) {
             const uint32_t b = (uint32_t)__builtin_ctzll(todo);
@@ -1328,7 +1346,8 @@ constexpr int kPickThreads = 1024;
 
 __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchState *bs, const SelList *sel,
                                                            unsigned long long *best, uint32_t n_target,
-                                                           uint32_t max_batch, uint32_t fused_min) {
+                                                           uint32_t max_batch, uint32_t fused_min,
+                                                           uint32_t n_ranks) {
     __shared__ unsigned long long sp[kSelCap];
     __shared__ uint32_t si[kSelCap];
     __shared__ uint32_t s_keys[kBatchMax];
@@ -1412,7 +1431,8 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         if (tid == 0) {
             ctl->batch_n = accepted;
             ctl->commit_n = accepted;
-            ctl->fused = accepted >= 2 && accepted >= fused_min ? 1u : 0u;
+            __threadfence_block();
+            ctl->fused = want_fused(bs, accepted, fused_min, ctl->n_live * n_ranks) ? 1u : 0u;
             ctl->n_batches += 1;
             ctl->sel_ok = 1;
             if (cut == 1u) ctl->cut_conflict += 1;
@@ -2460,15 +2480,15 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus) {
+                         int n_cus, int n_ranks) {
     if (sel) {
         const int blocks = (n_cus > 0 ? n_cus : 256) * 4;
         hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target);
         hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
-                           fused_min);
+                           fused_min, (uint32_t)n_ranks);
     }
     hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch,
-                       fused_min);
+                       fused_min, (uint32_t)n_ranks);
 }
 
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,

@@ -192,7 +192,7 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 // prefix), then k_select_batch (walks the argmax bounds one pair at a time) if that could not be used
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus);
+                         int n_cus, int n_ranks);
 // small batch: count the deltas and mark the tiles (the rewrite follows validation)
 void launch_scan_batch(hipStream_t s, const uint16_t *tok0, const uint16_t *tok1, const TileSum *sums,
                        uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,

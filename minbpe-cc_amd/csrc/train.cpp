@@ -663,7 +663,8 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     const bool multi = is_multi(c);
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
     launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best,
-                        c->n_target, (uint32_t)c->opt_max_batch, (uint32_t)c->opt_fused_min, c->n_cus);
+                        c->n_target, (uint32_t)c->opt_max_batch, (uint32_t)c->opt_fused_min, c->n_cus,
+                        std::max(1, c->n_ranks));
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     // (the live token buffer is ctl->cur: a fused pass flips it without the host knowing)
     launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
