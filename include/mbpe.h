@@ -82,6 +82,9 @@ typedef struct {
     float    ms_compact;       /* host wall time spent compacting the stream */
     uint32_t n_table_grows;
     uint32_t n_sel_fallback;   /* batches chosen by the bound-walking selection instead of the threshold gather */
+    uint32_t fused_launches;   /* fused passes timed ("time_kernels" option) */
+    float    ms_fused_kernel;  /* their summed duration */
+    uint64_t fused_slots;      /* stream slots those passes read (and wrote) */
 } mbpe_stats;
 
 MBPE_API const char *mbpe_last_error(void);
@@ -173,9 +176,18 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
 
 /* Tuning knobs (tests force rare paths with them).
  *   "compact_den"   compact when holes * den >= slots (default 8; 0 = never)
- *   "batch"         merges per host round trip (default 64)
- *   "use_graph"     1 = replay merges from a captured hipGraph (default 1)
+ *   "batch"         sequences (or single merges) per host round trip (default 64)
+ *   "multi_merge"   1 = several independent merges per stream pass (default), 0 = one
+ *   "max_batch"     most merges one pass may take (default and limit 128)
+ *   "fused_min"     batches of at least this many pairs read the stream once and write
+ *                   the merged stream to the second buffer (default 24; frequent pairs
+ *                   qualify earlier); 2 = every multi-pair batch, >= 1000 = never
+ *   "dense_table"   -1/1 one cell per possible pair when vocab <= 32,768 (default),
+ *                   0 = always the hashed pair table
+ *   "threshold_select" 1 = choose batches from a gathered, sorted candidate list
+ *                   (default), 0 = always walk the argmax bounds pair by pair
  *   "hier_argmax"   -1 auto / 0 scan every entry / 1 walk the block bounds
+ *                   (single-merge mode)
  *   "force_exchange" 1 = take the multi-rank path (rank edges, exchange) even
  *                   with a single rank (tests the RCCL binding on one GPU)
  *   "time_kernels"  1 = bracket every merge kernel with HIP events on the

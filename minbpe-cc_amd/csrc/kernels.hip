@@ -2120,8 +2120,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *tok0
 }
 
 // last kernel of a sequence: advance the merge counter
-__global__ void k_seq_finish(DevCtl *ctl) {
+__global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag) {
     if (blockIdx.x || threadIdx.x) return;
+    if (fused_flag) *fused_flag = ctl->fused && ctl->batch_n >= 2 ? 1u : 0u;
     if (ctl->batch_n >= 2) {       // (a single-pair batch was accounted by k_apply)
         const uint32_t rm = ctl->rm;
         ctl->removed_total += rm;
@@ -2588,8 +2589,8 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok, uint16_t *tok1, const T
                            left_edge, right_edge);
 }
 
-void launch_seq_finish(hipStream_t s, DevCtl *ctl) {
-    hipLaunchKernelGGL(k_seq_finish, dim3(1), dim3(64), 0, s, ctl);
+void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag) {
+    hipLaunchKernelGGL(k_seq_finish, dim3(1), dim3(64), 0, s, ctl, fused_flag);
 }
 
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles, unsigned long long *offsets,

@@ -209,7 +209,8 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 void launch_rewrite_marked(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side, uint32_t n_tiles,
                            uint32_t *chg, uint32_t *list /* [n_tiles] scratch */, const BatchState *bs, DevCtl *ctl,
                            const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus);
-void launch_seq_finish(hipStream_t s, DevCtl *ctl);
+// fused_flag (optional): set to 1 when this sequence ran the fused pass
+void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag);
 
 // compaction: exclusive scan of n_live over tiles, then scatter.  `offsets` needs
 // n_tiles + tile_scan_scratch(n_tiles) entries.

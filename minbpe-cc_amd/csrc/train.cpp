@@ -137,6 +137,7 @@ struct mbpe_ctx {
     uint32_t *chg = nullptr;     // bitmap of those tiles
     uint32_t *tile_list = nullptr;   // the same as a dense list (batch rewrite pass)
     SelList *sel = nullptr;          // candidates of the threshold selection
+    int seq_slot = -1;               // index of the sequence being enqueued within its group (opt_time_kernels)
     unsigned long long *offsets = nullptr;
 
     // pair table
@@ -185,6 +186,9 @@ struct mbpe_ctx {
     int64_t opt_dense_table = -1;   // -1 auto / 1: dense pair table when vocab <= 32,768; 0: always hashed
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
+    std::vector<hipEvent_t> kev_f;  // ... around the fused pass alone
+    uint32_t *seq_flags = nullptr;  // per sequence of a group: 1 = a fused pass ran (opt_time_kernels)
+    std::vector<uint32_t> h_seq_flags;
 
     mbpe_stats stats = {};
 };
@@ -215,7 +219,7 @@ void free_training(mbpe_ctx *c) {
     dfree(c->tab.hslot); dfree(c->tab.ekey); dfree(c->tab.ecnt); dfree(c->tab.cells);
     dfree(c->tab.bmax); dfree(c->tab.smax);
     dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->xb); dfree(c->xb0);
-    dfree(c->d_left); dfree(c->d_right); dfree(c->bs); dfree(c->sel);
+    dfree(c->d_left); dfree(c->d_right); dfree(c->bs); dfree(c->sel); dfree(c->seq_flags);
     c->LR = nullptr;
     c->pending = 0;
     c->begun = false;
@@ -379,6 +383,7 @@ void mbpe_destroy(mbpe_ctx *c) {
     free_corpus(c);
     if (c->nccl_comm && rccl().ok) rccl().CommDestroy(c->nccl_comm);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->kev_f) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -563,6 +568,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     c->LR = c->xb + c->hdr_words + c->hdrb_words;
     HIPCHK(hipMalloc(&c->bs, sizeof(BatchState)));
     HIPCHK(hipMalloc(&c->sel, sizeof(SelList)));
+    HIPCHK(hipMalloc(&c->seq_flags, 4096 * 4));
     HIPCHK(hipMemsetAsync(c->bs, 0, sizeof(BatchState), c->stream));
     c->k_upper = 0;
     c->bp = nullptr;   // the byte-pair table lives at the front of xb0
@@ -671,9 +677,13 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
                  multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1);
     launch_scan_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
                       c->ctl, le, re, endbit, c->n_cus);
+    if (ev_slot >= 0) (void)hipEventRecord(c->kev_f[2 * ev_slot], c->stream);
     launch_fused_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->bs, c->hdr_adj, c->LR,
                        c->ctl, le, re, endbit, c->n_cus);
-    if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
+    if (ev_slot >= 0) {
+        (void)hipEventRecord(c->kev_f[2 * ev_slot + 1], c->stream);
+        (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
+    }
 }
 
 static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge exchange
@@ -688,7 +698,7 @@ static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge excha
     launch_rewrite_marked(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->tile_list, c->bs, c->ctl, le, re,
                           endbit, c->n_cus);
     launch_patch_sums(c->stream, c->best, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 1);
-    launch_seq_finish(c->stream, c->ctl);
+    launch_seq_finish(c->stream, c->ctl, c->seq_slot >= 0 ? c->seq_flags + c->seq_slot : nullptr);
     if (multi)
         launch_rank_edge(c->stream, c->sums, c->n_tiles, reinterpret_cast<RankEdge *>(c->xb + 2) + c->rank, c->ctl,
                          c->xb);
@@ -706,7 +716,7 @@ static uint64_t seq_headroom(const mbpe_ctx *c) {
 // sequences between two host synchronisations: bounded by the "batch" option and by
 // the table headroom they need (8M entries at most)
 static uint32_t seqs_per_sync(const mbpe_ctx *c) {
-    if (c->tab.cells) return (uint32_t)std::max<int64_t>(1, c->opt_batch);    // nothing to reserve
+    if (c->tab.cells) return (uint32_t)std::min<int64_t>(4096, std::max<int64_t>(1, c->opt_batch));   // nothing to reserve
     uint64_t g = (8ull << 20) / seq_headroom(c);
     g = std::max<uint64_t>(1, std::min<uint64_t>(g, (uint64_t)c->opt_batch));
     return (uint32_t)g;
@@ -772,6 +782,11 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
                 HIPCHK(hipEventCreate(&e));
                 c->kev.push_back(e);
             }
+            while (c->kev_f.size() < 2ull * group) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));
+                c->kev_f.push_back(e);
+            }
         }
         c->k_upper = c->k;
         const uint32_t batches_before = c->h_ctl.n_batches;
@@ -784,6 +799,7 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
                                                       c->n_target, c->k_upper + (uint32_t)c->opt_max_batch)));
                 if (rc != MBPE_OK) return rc;
             }
+            c->seq_slot = c->opt_time_kernels ? (int)g : -1;
             seq_stage_b(c);
             if (is_multi(c)) {
                 int rc = comm_allreduce(c, c->xb, c->hdr_words);
@@ -791,6 +807,7 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
             }
             seq_stage_c(c);
         }
+        c->seq_slot = -1;
         HIPCHK(hipEventRecord(c->ev1, c->stream));
         int rc = sync_ctl(c);
         if (rc != MBPE_OK) return rc;
@@ -799,10 +816,19 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
         HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->stats.ms_steps += ms;
         if (c->opt_time_kernels) {
+            c->h_seq_flags.resize(launched);
+            if (launched)
+                HIPCHK(hipMemcpy(c->h_seq_flags.data(), c->seq_flags, launched * 4, hipMemcpyDeviceToHost));
             for (uint32_t g = 0; g < launched; ++g) {
                 float km = 0;
                 HIPCHK(hipEventElapsedTime(&km, c->kev[2 * g], c->kev[2 * g + 1]));
                 c->stats.ms_merge_kernel += km;
+                if (c->h_seq_flags[g]) {          // this sequence ran the fused pass
+                    HIPCHK(hipEventElapsedTime(&km, c->kev_f[2 * g], c->kev_f[2 * g + 1]));
+                    c->stats.ms_fused_kernel += km;
+                    c->stats.fused_launches++;
+                    c->stats.fused_slots += c->n_slots;
+                }
             }
             c->stats.merge_launches += c->h_ctl.n_batches - batches_before;   // sequences that did work
         }

@@ -33,11 +33,15 @@ def main():
             k = short(r["Kernel_Name"])
             if k:
                 agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
-        print("kernel,counter,dispatches,avg_KB,min_KB,max_KB,avg_bytes_raw,avg_bytes_corrected")
+        # Most launches of the batch-sequence kernels return at once (every sequence launches all of
+        # them and the device decides which one works): averages are over the WORKING dispatches,
+        # those that moved at least 1 % of the largest one.
+        print("kernel,counter,dispatches,working,avg_KB,min_KB,max_KB,avg_bytes_raw,avg_bytes_corrected")
         for (k, c), v in sorted(agg.items()):
-            avg = sum(v) / len(v)
+            w = [x for x in v if x >= 0.01 * max(v)] if max(v) > 0 else v
+            avg = sum(w) / len(w)
             corr = avg * 1024 * (2 if c == "FETCH_SIZE" else 1)
-            print("%s,%s,%d,%.1f,%.1f,%.1f,%.0f,%.0f" % (k, c, len(v), avg, min(v), max(v), avg * 1024, corr))
+            print("%s,%s,%d,%d,%.1f,%.1f,%.1f,%.0f,%.0f" % (k, c, len(v), len(w), avg, min(w), max(w), avg * 1024, corr))
 
 
 if __name__ == "__main__":
