@@ -2011,6 +2011,105 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
     }
 }
 
+// The same for the dense pair table, arranged so that three of the four updates per delta are
+// contiguous.  A workgroup takes 64 ids x and 64 pairs j through LDS:
+//   lanes along j:  (x, a_j) -= L   (scattered over row x)     (x, X_j)  = L   (64 consecutive cells of row x)
+//   lanes along x:  (b_j, x) -= R   (64 consecutive cells of row b_j)   (X_j, x) = R   (... of row X_j)
+// A new token's pairs are plain stores; their argmax bounds are raised once per wave.
+constexpr int kApplyTile = 64;
+
+__device__ __forceinline__ void dense_insert_run(const PairTable &t, DevCtl *ctl, bool active, uint32_t e,
+                                                 uint32_t key, uint32_t count) {
+    // lanes hold consecutive cells e (same row); active lanes insert count
+    if (active) t.cells[e] = kPresent | count;
+    const unsigned long long m = __ballot(active);
+    if (!m) return;
+    unsigned long long p = active ? pack_best((int32_t)count, key) : 0ull;
+    const uint32_t blk = e >> kBlockShift;
+    const uint32_t blk0 = rfl(__shfl(blk, (uint32_t)__builtin_ctzll(m), kWave));
+    if (__ballot(active && blk != blk0) == 0ull) {       // one bound block (the usual case)
+        p = wave_max_u64(p);
+        if (lane_id() == 0) {
+            atomicAdd(&ctl->n_entries, (uint32_t)__popcll(m));
+            if (p > t.bmax[blk0]) atomicMax(&t.bmax[blk0], p);
+            if (p > t.smax[blk0 >> kBlockShift]) atomicMax(&t.smax[blk0 >> kBlockShift], p);
+        }
+    } else if (active) {
+        atomicAdd(&ctl->n_entries, 1u);
+        if (p > t.bmax[blk]) atomicMax(&t.bmax[blk], p);
+        if (p > t.smax[blk >> kBlockShift]) atomicMax(&t.smax[blk >> kBlockShift], p);
+    }
+}
+
+__device__ __forceinline__ void dense_decrement(const PairTable &t, DevCtl *ctl, uint32_t e, uint32_t by) {
+    const uint32_t old = atomicAdd(&t.cells[e], 0u - by);
+    if (!(old & kPresent)) atomicOr(&ctl->err, kErrMissingPair);
+    else if ((old & ~kPresent) < by) atomicOr(&ctl->err, kErrNegCount);
+}
+
+__global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *ctl, const BatchState *bs,
+                                                           uint32_t *hdr_adj, uint32_t *LR) {
+    __shared__ uint2 tile[kApplyTile][kApplyTile + 1];
+    const uint32_t n = ctl->batch_n;
+    if (n < 2) return;
+    const uint32_t commit = ctl->commit_n;
+    const uint32_t X0 = 256u + ctl->k_done;
+    constexpr uint32_t j_parts = kBatchMax / kApplyTile;
+    const uint32_t x0 = (blockIdx.x / j_parts) * kApplyTile, j0 = (blockIdx.x % j_parts) * kApplyTile;
+    const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
+    if (x0 < X0 && j0 < n) {
+        // load (and clear) the deltas of ids x0.. and pairs j0..: rows along j are contiguous in LR
+        for (uint32_t r = wave; r < (uint32_t)kApplyTile; r += 256 / kWave) {
+            const uint32_t x = x0 + r, j = j0 + lane;
+            uint2 lr = make_uint2(0, 0);
+            if (x < X0 && j < n) {
+                uint2 *cell = reinterpret_cast<uint2 *>(LR) + ((uint64_t)x * kBatchMax + j);
+                lr = *cell;
+                if (lr.x | lr.y) *cell = make_uint2(0, 0);
+                if (j >= commit) lr = make_uint2(0, 0);
+            }
+            tile[r][lane] = lr;
+        }
+        __syncthreads();
+        const uint32_t pitch_shift = t.vshift;
+        // lanes along j: left neighbours x
+        for (uint32_t r = wave; r < (uint32_t)kApplyTile; r += 256 / kWave) {
+            const uint32_t x = x0 + r, j = j0 + lane;
+            const uint32_t l = tile[r][lane].x;
+            const uint32_t a = j < n ? bs->key[j] >> 16 : 0u;
+            if (l) dense_decrement(t, ctl, (x << pitch_shift) | a, l);
+            dense_insert_run(t, ctl, l != 0u, (x << pitch_shift) | (X0 + j), (x << 16) | (X0 + j), l);
+        }
+        // lanes along x: right neighbours x
+        for (uint32_t c = wave; c < (uint32_t)kApplyTile; c += 256 / kWave) {
+            const uint32_t x = x0 + lane, j = j0 + c;
+            if (j >= n) break;
+            const uint32_t rr = tile[lane][c].y;
+            const uint32_t b = bs->key[j] & 0xFFFFu, X = X0 + j;
+            if (rr) dense_decrement(t, ctl, (b << pitch_shift) | x, rr);
+            dense_insert_run(t, ctl, rr != 0u, (X << pitch_shift) | x, (X << 16) | x, rr);
+        }
+    }
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < (uint64_t)kBatchMax * kBatchMax) {
+        const uint32_t p = (uint32_t)gid / kBatchMax, j = (uint32_t)gid % kBatchMax;
+        const uint32_t adj = hdr_adj[gid];
+        if (adj) {
+            hdr_adj[gid] = 0;
+            if (p < commit && j < commit) {     // match of p directly followed by a match of j
+                const uint32_t bp = bs->key[p] & 0xFFFFu, aj = bs->key[j] >> 16;
+                table_add(t, ctl, (bp << 16) | aj, -(int32_t)adj, false);
+                table_add(t, ctl, ((X0 + p) << 16) | (X0 + j), (int32_t)adj, true);
+            }
+        }
+    }
+    if (gid < commit) {
+        // every occurrence of an (a,b), a != b, pair is merged: its count drops to 0
+        const uint32_t m = (uint32_t)(bs->packed[gid] >> 32);
+        if (m) table_add(t, ctl, bs->key[gid], -(int32_t)m, false);
+    }
+}
+
 // The rewriting half: tiles marked by the scan pass, pairs of the validated prefix.
 // k_list_marked turns the bitmap into a dense list so that k_rewrite_marked can
 // walk it with the same prefetch ring as the streaming passes.
@@ -2571,7 +2670,14 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     if (blocks < 2) blocks = 2;
     hipLaunchKernelGGL(k_delta_max, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, LR, bs, ctl);
     hipLaunchKernelGGL(k_validate, dim3(1), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
-    hipLaunchKernelGGL(k_apply_batch, dim3(blocks), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
+    if (t.cells) {
+        uint32_t grid = ((id_upper + kApplyTile - 1) / kApplyTile) * (kBatchMax / kApplyTile);
+        const uint32_t need = (kBatchMax * kBatchMax + 255) / 256;          // the ADJ cells, one thread each
+        if (grid < need) grid = need;
+        hipLaunchKernelGGL(k_apply_batch_dense, dim3(grid), dim3(256), 0, s, t, ctl, bs, hdr_adj, LR);
+    } else {
+        hipLaunchKernelGGL(k_apply_batch, dim3(blocks), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
+    }
 }
 
 void launch_rewrite_marked(hipStream_t s, uint16_t *tok, uint16_t *tok1, const TileSum *sums, TileSum *side, uint32_t n_tiles,
