@@ -137,6 +137,9 @@ def main():
     torch.cuda.synchronize()
 
     tr = mbpe.Trainer(local_rank)
+    for kv in filter(None, os.environ.get("MBPE_BENCH_OPTS", "").split(",")):     # e.g. fused_min=16,max_batch=64
+        k, v = kv.split("=")
+        tr.set_option(k, int(v))
     if world > 1:
         uid = [mbpe.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
