@@ -1364,15 +1364,17 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         return;
     }
     if (T == 0ull || n_l == 0 || n_l > kSelCap) return;     // not primed / nothing above T / overflow
-    for (uint32_t i = tid; i < kSelCap; i += kPickThreads) {
+    uint32_t n_sort = 64;                       // power of two >= n_l
+    while (n_sort < n_l) n_sort <<= 1;
+    for (uint32_t i = tid; i < n_sort; i += kPickThreads) {
         sp[i] = i < n_l ? sel->packed[i] : 0ull;
         si[i] = i < n_l ? sel->eidx[i] : 0u;
     }
     __syncthreads();
     // bitonic sort, descending by packed value (unique per pair: a total order)
-    for (uint32_t k = 2; k <= kSelCap; k <<= 1) {
+    for (uint32_t k = 2; k <= n_sort; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < kSelCap; i += kPickThreads) {
+            for (uint32_t i = tid; i < n_sort; i += kPickThreads) {
                 const uint32_t l = i ^ j;
                 if (l > i) {
                     const bool desc = (i & k) == 0;
