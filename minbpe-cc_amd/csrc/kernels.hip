@@ -1134,6 +1134,18 @@ __device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, u
     return bk.x == kk || bk.y == kk;
 }
 
+// The same test in the streaming loops, written so that it costs few VALU instructions:
+// hash with one v_mad_u32_u24, no boolean materialised.  Returns 0 iff (first, second) is a
+// batch pair, something non-zero otherwise.
+__device__ __forceinline__ uint32_t pair_miss(const BatchLut &lut, uint32_t first, uint32_t second) {
+    uint32_t h;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(2531u), "v"(first));
+    const uint2 bk = lut.bucket[h & (kBuckets - 1u)];
+    const uint32_t kk = first | (second << 16);
+    const uint32_t dx = bk.x ^ kk, dy = bk.y ^ kk;
+    return dx < dy ? dx : dy;
+}
+
 // index of the pair (only called for pairs that passed pair_test)
 __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, uint32_t second) {
     const uint32_t h = pair_hash(first, second);
@@ -1627,12 +1639,14 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
             const unsigned long long hi = m_live & gt_mask;
             const uint32_t nf = __shfl(lf, hi ? (uint32_t)__builtin_ctzll(hi) : lane, kWave);
             uint32_t c = hi ? nf : h.n1;
-            bool cand = false;
+            uint32_t miss = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                cand |= pair_test(lut, s[j], c & idmask);
+                const uint32_t d = pair_miss(lut, s[j], c & idmask);
+                miss = d < miss ? d : miss;
                 c = s[j] != kHole ? s[j] : c;
             }
+            const bool cand = miss == 0u;
             // (also: a match whose first token is the previous tile's last live token)
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             bool work = __ballot(cand) != 0ull || pair_test(lut, h.p1, tile_first & idmask);
@@ -1839,19 +1853,18 @@ __global__ __launch_bounds__(kMergeThreads) void k_fused_batch(uint16_t *tok0, u
             const uint32_t c_init = hi ? nf : h.n1;
             uint32_t c = c_init;
             uint32_t cj[8];
-            bool hit[8];
+            uint32_t nohit = 0;          // bit j clear <=> slot j starts a match
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
                 cj[j] = c;
-                hit[j] = pair_test(lut, s[j], c & idmask);
+                const uint32_t d = pair_miss(lut, s[j], c & idmask);
+                nohit = (nohit << 1) | (d < 1u ? d : 1u);
                 c = s[j] != kHole ? s[j] : c;
             }
-            const bool any = hit[0] | hit[1] | hit[2] | hit[3] | hit[4] | hit[5] | hit[6] | hit[7];
+            const bool any = nohit != 0xFFu;
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
-                uint32_t Am = 0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) Am |= (hit[j] ? 1u : 0u) << j;
+                const uint32_t Am = nohit ^ 0xFFu;
                 outq = fused_tile_full<CHUNKED, DIAG>(s, cj, Am, m_live, c_init, h, tile_first, old_x, old_y, old_z, lut,
                                                 X0, tile, sout, chg, hdr_adj, LR, dc, dc_on, wave_rm);
             }
