@@ -727,25 +727,25 @@ __global__ void k_table_rehash(PairTable t, DevCtl *ctl) {      // hashed layout
 
 struct TileIn {
     uint4 q;    // this lane's 8 slots
-    uint4 sm;   // lanes 0,1,2: summaries of tile-1, tile, tile+1 (one 16-byte load, 3 lanes active)
+    uint32_t smw;   // lanes 0..11: the 12 dwords of the summaries of tile-1, tile, tile+1 (lane = 4 * k + word)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Both loads are unconditional: a branch around a load makes hipcc wait
 // vmcnt(0) at the next use, which would drain the tiles prefetched behind
-// this one.  The three summaries come through a bounds-checked buffer load:
-// lanes 0..2 read tile-1 .. tile+1, every other lane (and a neighbour that
-// does not exist) points past the buffer and gets zeros without any traffic.
+// this one.  The three summaries come through a bounds-checked buffer load of
+// one dword per lane (a tile in flight then costs 5 registers, not 8): lanes
+// 0..11 read the 12 words of tile-1 .. tile+1, every other lane (and a neighbour
+// that does not exist) points past the buffer and gets zeros without any traffic.
 __device__ __forceinline__ TileIn tile_issue(const uint16_t *tok, __amdgpu_buffer_rsrc_t sums_rsrc,
                                              uint32_t tile) {
     TileIn t;
     const uint32_t lane = lane_id();
     t.q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kWave + lane];
-    const uint32_t j = tile + lane - 1u;                       // tile 0, lane 0 wraps to 0xFFFFFFFF
-    const uint32_t off = (lane < 3 && j < 0x0FFFFFFFu) ? j * 16u : 0xFFFFFFF0u;
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sums_rsrc, off, 0, 0);
-    t.sm = make_uint4(v.x, v.y, v.z, v.w);
+    const uint32_t j = tile + (lane >> 2) - 1u;                // tile 0, lanes 0..3 wrap to 0xFFFFFFFF
+    const uint32_t off = (lane < 12 && j < 0x0FFFFFFFu) ? j * 16u + (lane & 3u) * 4u : 0xFFFFFFF0u;
+    t.smw = __builtin_amdgcn_raw_buffer_load_b32(sums_rsrc, off, 0, 0);
     return t;
 }
 
@@ -942,16 +942,16 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
         TileIn t3 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 3ull * n_waves));
 
         // ---- this tile -------------------------------------------------------
-        const uint32_t me_nlive = rlane(t0.sm.z, 1) & 0xFFFFu;
+        const uint32_t me_nlive = rlane(t0.smw, 6) & 0xFFFFu;
         if (DIAG == 1) {   // timing-only build: loads only
-            asm volatile("" :: "v"(t0.q.x), "v"(t0.q.y), "v"(t0.q.z), "v"(t0.q.w), "v"(t0.sm.x), "v"(t0.sm.y));
+            asm volatile("" :: "v"(t0.q.x), "v"(t0.q.y), "v"(t0.q.z), "v"(t0.q.w), "v"(t0.smw));
         } else if (me_nlive != 0) {
             uint32_t s[8];
             unpack8(t0.q, s);
             // neighbours' edge tokens
             Halo h;
-            const uint32_t pw1 = rlane(t0.sm.y, 0), pw2 = rlane(t0.sm.z, 0);
-            const uint32_t nw0 = rlane(t0.sm.x, 2), nw2 = rlane(t0.sm.z, 2);
+            const uint32_t pw1 = rlane(t0.smw, 1), pw2 = rlane(t0.smw, 2);
+            const uint32_t nw0 = rlane(t0.smw, 8), nw2 = rlane(t0.smw, 10);
             const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
             if (fast) {
                 h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
@@ -1614,15 +1614,15 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
         const bool v3 = (uint64_t)tile + 3ull * n_waves < n_tiles;
         TileIn t3 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 3ull * n_waves));
 
-        const uint32_t me_nlive = rlane(t0.sm.z, 1) & 0xFFFFu;
+        const uint32_t me_nlive = rlane(t0.smw, 6) & 0xFFFFu;
         if (DIAG == 1) {
-            asm volatile("" :: "v"(t0.q.x), "v"(t0.q.y), "v"(t0.q.z), "v"(t0.q.w), "v"(t0.sm.x), "v"(t0.sm.y));
+            asm volatile("" :: "v"(t0.q.x), "v"(t0.q.y), "v"(t0.q.z), "v"(t0.q.w), "v"(t0.smw));
         } else if (me_nlive != 0) {
             uint32_t s[8];
             unpack8(t0.q, s);
             Halo h;
-            const uint32_t pw1 = rlane(t0.sm.y, 0), pw2 = rlane(t0.sm.z, 0);
-            const uint32_t nw0 = rlane(t0.sm.x, 2), nw2 = rlane(t0.sm.z, 2);
+            const uint32_t pw1 = rlane(t0.smw, 1), pw2 = rlane(t0.smw, 2);
+            const uint32_t nw0 = rlane(t0.smw, 8), nw2 = rlane(t0.smw, 10);
             const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
             if (fast) {
                 h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
@@ -1832,13 +1832,13 @@ __global__ __launch_bounds__(kMergeThreads, 6) void k_fused_batch(uint16_t *tok0
         TileIn t3 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 3ull * n_waves));
 
         uint4 outq = t0.q;
-        const uint32_t old_x = rlane(t0.sm.x, 1), old_y = rlane(t0.sm.y, 1), old_z = rlane(t0.sm.z, 1);
+        const uint32_t old_x = rlane(t0.smw, 4), old_y = rlane(t0.smw, 5), old_z = rlane(t0.smw, 6);
         if ((old_z & 0xFFFFu) != 0) {
             uint32_t s[8];
             unpack8(t0.q, s);
             Halo h;
-            const uint32_t pw1 = rlane(t0.sm.y, 0), pw2 = rlane(t0.sm.z, 0);
-            const uint32_t nw0 = rlane(t0.sm.x, 2), nw2 = rlane(t0.sm.z, 2);
+            const uint32_t pw1 = rlane(t0.smw, 1), pw2 = rlane(t0.smw, 2);
+            const uint32_t nw0 = rlane(t0.smw, 8), nw2 = rlane(t0.smw, 10);
             const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
             if (fast) {
                 h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
@@ -2186,8 +2186,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *tok0
         uint32_t s[8];
         unpack8(t0.q, s);
         Halo h;
-        const uint32_t pw1 = rlane(t0.sm.y, 0), pw2 = rlane(t0.sm.z, 0);
-        const uint32_t nw0 = rlane(t0.sm.x, 2), nw2 = rlane(t0.sm.z, 2);
+        const uint32_t pw1 = rlane(t0.smw, 1), pw2 = rlane(t0.smw, 2);
+        const uint32_t nw0 = rlane(t0.smw, 8), nw2 = rlane(t0.smw, 10);
         const bool fast = tile > 0 && tile + 1 < n_tiles && (pw2 & 0xFFFFu) >= 2 && (nw2 & 0xFFFFu) >= 2;
         if (fast) {
             h.p1 = pw1 >> 16; h.p2 = pw1 & 0xFFFFu;
