@@ -1642,7 +1642,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
             uint32_t miss = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                const uint32_t d = pair_miss(lut, s[j], c & idmask);
+                const uint32_t d = pair_miss(lut, s[j], CHUNKED ? c & idmask : c);    // (ids are 16-bit: no mask needed)
                 miss = d < miss ? d : miss;
                 c = s[j] != kHole ? s[j] : c;
             }
@@ -1734,31 +1734,29 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
     }
 
     uint32_t out[8];
+    const uint32_t ABm = Am | Bm;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t self = s[j];
         uint32_t nv = self;
-        if ((Am >> j) & 1u) {                             // first token of a match
-            const uint32_t ja = (uint32_t)lut_index(lut, self, cj[j] & idmask);
-            nv = (X0 + ja) | (cj[j] & endbit);
-            if (p1 != kHole && !(p1 & endbit)) {
-                if (DIAG == 2) {                          // timing-only build: no delta atomics
-                    asm volatile("" :: "v"(p1), "v"(ja), "v"(pjb));
-                } else if ((touch >> j) & 1u) {           // ... (a', b') (a, b): (b', a) -> (X', X)
+        if ((ABm >> j) & 1u) {               // one guarded region per position serves both roles
+            const bool is_a = (Am >> j) & 1u;
+            uint32_t ja = pj;
+            if (is_a) ja = (uint32_t)lut_index(lut, self, cj[j] & idmask);
+            // first token of a match: (p1, a) -> (p1, X); second token: (b, n1) -> (X, n1)
+            const uint32_t nb = is_a ? p1 : cj[j];                       // the neighbour the match loses
+            const bool counted = is_a ? (p1 != kHole && !(p1 & endbit)) : (!(self & endbit) && cj[j] != kHole);
+            nv = is_a ? (X0 + ja) | (cj[j] & endbit) : kHole;
+            if (counted && DIAG != 2) {
+                if (is_a && ((touch >> j) & 1u)) {        // ... (a', b') (a, b): (b', a) -> (X', X)
                     atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
-                    dc_add(dc, dc_on, LR, lr_idx(self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b') below
+                    dc_add(dc, dc_on, LR, lr_idx(self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b')
                 } else {
-                    dc_add(dc, dc_on, LR, lr_idx(p1, ja, 0), 1u);
+                    dc_add(dc, dc_on, LR, lr_idx(nb & idmask, ja, is_a ? 0u : 1u), 1u);
                 }
             }
+            pjb = is_a ? pjb : pj;
             pj = ja;
-        } else if ((Bm >> j) & 1u) {                      // second token of a match
-            nv = kHole;
-            if (!(self & endbit) && cj[j] != kHole) {
-                if (DIAG == 2) asm volatile("" :: "v"(cj[j]), "v"(pj));
-                else dc_add(dc, dc_on, LR, lr_idx(cj[j] & idmask, pj, 1), 1u);
-            }
-            pjb = pj;
         }
         p1 = self != kHole ? self : p1;
         out[j] = nv;
@@ -1768,7 +1766,6 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
     wave_rm += removed;
     // New summary.  Heads and tails only change when a match touches one of the first two or
     // last two live tokens; a trailing run of equal tokens (tail_run > 1) is recounted.
-    const uint32_t ABm = Am | Bm;
     const uint32_t top = Lm ? 31u - (uint32_t)__builtin_clz(Lm) : 0u;
     const uint32_t lb1 = Lm & (0u - Lm), r1 = Lm ^ lb1, lb2 = r1 & (0u - r1);
     const uint32_t hb1 = Lm ? 1u << top : 0u, r2 = Lm ^ hb1, hb2 = r2 ? 1u << (31u - (uint32_t)__builtin_clz(r2)) : 0u;
