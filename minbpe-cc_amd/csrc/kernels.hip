@@ -1099,9 +1099,10 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 constexpr uint32_t kBuckets = 2048;
 constexpr uint32_t kEmptyPair = 0xFFFEFFFEu;
 
+static_assert(kBatchMax <= 256, "batch indices are stored in bytes");
 struct BatchLut {
     uint2 bucket[kBuckets];
-    uint32_t bidx[kBuckets];     // batch index of bucket.x (low half) and bucket.y (high half)
+    uint16_t bidx[kBuckets];     // batch index of bucket.x (low byte) and bucket.y (high byte)
 };
 
 __device__ __forceinline__ uint32_t pair_hash(uint32_t first, uint32_t second) {
@@ -1119,8 +1120,8 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
             const uint32_t key = bs->key[j];
             const uint32_t a = key >> 16, b = key & 0xFFFFu, h = pair_hash(a, b);
             const uint32_t kk = a | (b << 16);
-            if (lut.bucket[h].x == kEmptyPair) { lut.bucket[h].x = kk; lut.bidx[h] = j; }
-            else { lut.bucket[h].y = kk; lut.bidx[h] |= j << 16; }
+            if (lut.bucket[h].x == kEmptyPair) { lut.bucket[h].x = kk; lut.bidx[h] = (uint16_t)j; }
+            else { lut.bucket[h].y = kk; lut.bidx[h] = (uint16_t)(lut.bidx[h] | (j << 8)); }
         }
     }
     __syncthreads();
@@ -1150,7 +1151,7 @@ __device__ __forceinline__ uint32_t pair_miss(const BatchLut &lut, uint32_t firs
 __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, uint32_t second) {
     const uint32_t h = pair_hash(first, second);
     const uint32_t ix = lut.bidx[h];
-    return (int)(lut.bucket[h].x == (first | (second << 16)) ? ix & 0xFFFFu : ix >> 16);
+    return (int)(lut.bucket[h].x == (first | (second << 16)) ? ix & 0xFFu : ix >> 8);
 }
 
 // Which pass merges a multi-pair batch: the fused one (reads the stream once, writes all of it to
