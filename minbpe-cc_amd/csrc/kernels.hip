@@ -2544,7 +2544,8 @@ void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileS
                   DevCtl *ctl, uint32_t *m_adj, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus,
                   int seq) {
     if (!n_tiles) return;
-    const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
+    static const int occ_c = resident_blocks(k_merge<true, false, 0>), occ_b = resident_blocks(k_merge<false, false, 0>);
+    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_MERGE_DIAG") ? atoi(getenv("MBPE_MERGE_DIAG")) : 0;
     if (diag == 1 && !endbit) {
@@ -2639,7 +2640,9 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
                        const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
                        int n_cus) {
     if (!n_tiles) return;
-    const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
+    static const int occ_c = resident_blocks(k_scan_batch<true, false, 0>),
+                     occ_b = resident_blocks(k_scan_batch<false, false, 0>);
+    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_SCAN_DIAG") ? atoi(getenv("MBPE_SCAN_DIAG")) : 0;
     if (diag == 1 && !endbit) {
