@@ -1184,6 +1184,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
     uint32_t limit = k_limit - k0;
     if (limit > max_batch) limit = max_batch;
     if (limit > (uint32_t)kBatchMax) limit = kBatchMax;
+    if (ctl->adapt_limit && limit > ctl->adapt_limit) limit = ctl->adapt_limit;
     const uint32_t n_blocks = (n + kBlockSize - 1) >> kBlockShift;
     const uint32_t n_super = (n_blocks + kBlockSize - 1) >> kBlockShift;
     auto ld = [](const unsigned long long *p) {
@@ -1313,7 +1314,9 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
 // all gathered ones.  T only decides how many candidates come back; k_sel_pick adapts it, and
 // leaves the batch to k_select_batch when the list is empty or overflowed.
 
-__global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelList *sel, uint32_t n_target) {
+__global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelList *sel, uint32_t n_target,
+                                                  int attempt) {
+    if (attempt == 1 && (ctl->sel_ok || !ctl->sel_retry)) return;
     const unsigned long long T = ctl->sel_T;
     const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
     if (T == 0ull || ctl->k_done >= k_limit) return;
@@ -1360,23 +1363,24 @@ constexpr int kPickThreads = 1024;
 __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchState *bs, const SelList *sel,
                                                            unsigned long long *best, uint32_t n_target,
                                                            uint32_t max_batch, uint32_t fused_min,
-                                                           uint32_t n_ranks) {
+                                                           uint32_t n_ranks, int attempt) {
     __shared__ unsigned long long sp[kSelCap];
     __shared__ uint32_t si[kSelCap];
-    __shared__ uint32_t s_keys[kBatchMax];
-    __shared__ uint32_t s_acc;
     const uint32_t tid = threadIdx.x;
+    if (attempt == 1 && (ctl->sel_ok || !ctl->sel_retry)) return;
     const uint32_t k0 = ctl->k_done;
     const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
-    const uint32_t n_l = ctl->sel_n;
+    const uint32_t n_all = ctl->sel_n;          // entries >= T (the list holds the first kSelCap of them)
     const unsigned long long T = ctl->sel_T;
+    const uint32_t adapt = ctl->adapt_limit ? ctl->adapt_limit : (uint32_t)kBatchMax;
     __syncthreads();
-    if (tid == 0) { ctl->sel_n = 0; ctl->sel_ok = 0; }
+    if (tid == 0) { ctl->sel_n = 0; ctl->sel_ok = 0; ctl->sel_retry = 0; }
     if (k0 >= k_limit) {                       // nothing to select: the walking kernel returns at once too
         if (tid == 0) { ctl->batch_n = 0; ctl->commit_n = 0; ctl->fused = 0; }
         return;
     }
-    if (T == 0ull || n_l == 0 || n_l > kSelCap) return;     // not primed / nothing above T / overflow
+    if (T == 0ull || n_all == 0) return;        // not primed / nothing above T: the walking kernel takes over
+    const uint32_t n_l = n_all < kSelCap ? n_all : kSelCap;
     uint32_t n_sort = 64;                       // power of two >= n_l
     while (n_sort < n_l) n_sort <<= 1;
     for (uint32_t i = tid; i < n_sort; i += kPickThreads) {
@@ -1401,9 +1405,23 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             __syncthreads();
         }
     }
+    if (n_all > kSelCap) {
+        // Overflow (typically thousands of pairs with the same count): the list is an arbitrary
+        // sample of the entries >= T.  Its r-th largest value, r chosen so that about 3 batches'
+        // worth of the n_all entries rank above it, is the threshold of the second attempt.
+        if (attempt == 0 && tid == 0) {
+            unsigned long long r = (unsigned long long)kSelCap * (3ull * adapt) / n_all;
+            r = r < 1 ? 1 : (r > kSelCap - 1 ? kSelCap - 1 : r);
+            ctl->sel_T = sp[r];
+            ctl->sel_retry = 1;
+            ctl->n_sel_retry += 1;
+        }
+        return;
+    }
     uint32_t limit = k_limit - k0;
     if (limit > max_batch) limit = max_batch;
     if (limit > (uint32_t)kBatchMax) limit = kBatchMax;
+    if (limit > adapt) limit = adapt;
     // the independent prefix (one wave; lane i remembers accepted pairs i, i + 64, ...)
     if (tid < (uint32_t)kWave) {
         constexpr int kPer = (kBatchMax + kWave - 1) / kWave;
@@ -1456,7 +1474,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             if (cut == 0u && accepted == limit) ctl->cut_full += 1;
             // next threshold: about 128 candidates beyond this batch, or a window twice as wide
             // when the list ended before the batch was full
-            const uint32_t want = accepted + 2u * kBatchMax;
+            const uint32_t want = accepted + 2u * (adapt < 16u ? 16u : adapt);
             if (n_l > want) {
                 ctl->sel_T = sp[want];          // (the full packed value: also cuts inside a run of equal counts)
             } else {
@@ -2243,6 +2261,14 @@ __global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag) {
         ctl->n_live -= rm;
         ctl->rm = 0;
     }
+    if (ctl->batch_n >= 2) {
+        // learn how many pairs validation lets through: after a drop aim at twice what survived,
+        // after a full batch that hit the limit double it
+        uint32_t lim = ctl->adapt_limit ? ctl->adapt_limit : (uint32_t)kBatchMax;
+        if (ctl->commit_n < ctl->batch_n) lim = ctl->commit_n * 2u < 4u ? 4u : ctl->commit_n * 2u;
+        else if (ctl->batch_n >= lim) lim = lim * 2u;
+        ctl->adapt_limit = lim > (uint32_t)kBatchMax ? (uint32_t)kBatchMax : lim;
+    }
     if (ctl->fused && ctl->batch_n >= 2) {
         ctl->n_fused += 1;
         if (ctl->commit_n == ctl->batch_n) ctl->cur ^= 1u;   // the fused pass's output becomes the stream
@@ -2599,9 +2625,11 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
                          int n_cus, int n_ranks) {
     if (sel) {
         const int blocks = (n_cus > 0 ? n_cus : 256) * 4;
-        hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target);
-        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
-                           fused_min, (uint32_t)n_ranks);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target, attempt);
+            hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
+                               fused_min, (uint32_t)n_ranks, attempt);
+        }
     }
     hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch,
                        fused_min, (uint32_t)n_ranks);
