@@ -85,6 +85,9 @@ typedef struct {
     uint32_t fused_launches;   /* fused passes timed ("time_kernels" option) */
     float    ms_fused_kernel;  /* their summed duration */
     uint64_t fused_slots;      /* stream slots those passes read (and wrote) */
+    uint32_t n_sel_retry;      /* batches whose first candidate gather overflowed (threshold found among the block bounds) */
+    uint32_t adapt_limit;      /* current batch size limit learnt from validation */
+    uint64_t n_sel_blocks;     /* 1024-entry blocks of the pair table read by the candidate gathers */
 } mbpe_stats;
 
 MBPE_API const char *mbpe_last_error(void);

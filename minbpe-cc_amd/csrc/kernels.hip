@@ -1316,8 +1316,9 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
 
 __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelList *sel, uint32_t n_target,
                                                   int attempt) {
-    if (attempt == 1 && (ctl->sel_ok || !ctl->sel_retry)) return;
+    if (attempt > 0 && (ctl->sel_ok || !ctl->sel_retry)) return;
     const unsigned long long T = ctl->sel_T;
+    const bool bounds_only = ctl->sel_mode != 0;
     const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
     if (T == 0ull || ctl->k_done >= k_limit) return;
     const uint32_t n = table_size(t, ctl);
@@ -1325,24 +1326,46 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
     const uint32_t lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave, n_waves = gridDim.x * blockDim.x / kWave;
-    // a wave looks at g bounds at a time: 64 for a large table, fewer when there are not enough
-    // blocks to give every wave something to do
-    uint32_t g = n_blocks / n_waves;
-    g = g < 1u ? 1u : (g > (uint32_t)kWave ? (uint32_t)kWave : g);
-    for (uint64_t base = (uint64_t)wave * g; base < n_blocks; base += (uint64_t)n_waves * g) {
-        const uint32_t B = (uint32_t)base + lane;
-        const unsigned long long bound = lane < g && B < n_blocks
+    // Blocks are dealt out round robin (block B belongs to wave B mod n_waves): the blocks above
+    // the threshold are usually neighbours (the same few first tokens), and a wave reads its blocks
+    // one after the other.  The price is that the 64 bounds a wave looks at per step are strided.
+    for (uint64_t step = 0; step * n_waves * kWave < n_blocks; ++step) {
+        // far more entries than the list holds: no point in reading on, k_sel_pick will look for a
+        // better threshold among the block bounds
+        if (!bounds_only &&
+            __hip_atomic_load(&ctl->sel_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4u * kSelCap) break;
+        const uint64_t B64 = (step * kWave + lane) * n_waves + wave;
+        const uint32_t B = (uint32_t)B64;
+        const unsigned long long bound = B64 < n_blocks
             ? __hip_atomic_load(&t.bmax[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         unsigned long long todo = __ballot(bound >= T);
+        if (bounds_only) {
+            // looking for a threshold: list the block bounds themselves (8 bytes per 1024 entries)
+            if (todo) {
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&ctl->sel_n, (uint32_t)__popcll(todo));
+                at = rfl(at) + (uint32_t)__popcll(todo & lt_mask);
+                if (bound >= T && at < kSelCap) { sel->packed[at] = bound; sel->eidx[at] = B; }
+            }
+            continue;
+        }
         while (todo) {
+            if (__hip_atomic_load(&ctl->sel_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4u * kSelCap) break;
             const uint32_t b = (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1ull;
-            const uint32_t blk = (uint32_t)base + b;
+            const uint32_t blk = (uint32_t)((step * kWave + b) * n_waves + wave);
             unsigned long long mx = 0;
-#pragma unroll 4
+            // (all 16 loads of the block are issued before the first one is looked at)
+            unsigned long long pv[kBlockSize / kWave];
+#pragma unroll
             for (uint32_t q = 0; q < kBlockSize / kWave; ++q) {
                 const uint32_t e = (blk << kBlockShift) + q * kWave + lane;
-                const unsigned long long p = e < n ? entry_packed(t, e) : 0ull;
+                pv[q] = e < n ? entry_packed(t, e) : 0ull;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < kBlockSize / kWave; ++q) {
+                const uint32_t e = (blk << kBlockShift) + q * kWave + lane;
+                const unsigned long long p = pv[q];
                 mx = p > mx ? p : mx;
                 const unsigned long long hit = __ballot(p >= T && p != 0ull);
                 if (hit) {
@@ -1353,7 +1376,10 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
                 }
             }
             mx = wave_max_u64(mx);
-            if (lane == 0) __hip_atomic_store(&t.bmax[blk], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                __hip_atomic_store(&t.bmax[blk], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&ctl->n_sel_blocks, 1ull);
+            }
         }
     }
 }
@@ -1367,14 +1393,15 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
     __shared__ unsigned long long sp[kSelCap];
     __shared__ uint32_t si[kSelCap];
     const uint32_t tid = threadIdx.x;
-    if (attempt == 1 && (ctl->sel_ok || !ctl->sel_retry)) return;
+    if (attempt > 0 && (ctl->sel_ok || !ctl->sel_retry)) return;
     const uint32_t k0 = ctl->k_done;
     const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
     const uint32_t n_all = ctl->sel_n;          // entries >= T (the list holds the first kSelCap of them)
     const unsigned long long T = ctl->sel_T;
     const uint32_t adapt = ctl->adapt_limit ? ctl->adapt_limit : (uint32_t)kBatchMax;
+    const bool bounds_only = ctl->sel_mode != 0;
     __syncthreads();
-    if (tid == 0) { ctl->sel_n = 0; ctl->sel_ok = 0; ctl->sel_retry = 0; }
+    if (tid == 0) { ctl->sel_n = 0; ctl->sel_ok = 0; ctl->sel_retry = 0; ctl->sel_mode = 0; }
     if (k0 >= k_limit) {                       // nothing to select: the walking kernel returns at once too
         if (tid == 0) { ctl->batch_n = 0; ctl->commit_n = 0; ctl->fused = 0; }
         return;
@@ -1405,14 +1432,26 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             __syncthreads();
         }
     }
-    if (n_all > kSelCap) {
-        // Overflow (typically thousands of pairs with the same count): the list is an arbitrary
-        // sample of the entries >= T.  Its r-th largest value, r chosen so that about 3 batches'
-        // worth of the n_all entries rank above it, is the threshold of the second attempt.
-        if (attempt == 0 && tid == 0) {
-            unsigned long long r = (unsigned long long)kSelCap * (3ull * adapt) / n_all;
-            r = r < 1 ? 1 : (r > kSelCap - 1 ? kSelCap - 1 : r);
+    if (bounds_only) {
+        // The list holds block bounds, not entries (second attempt, after the entry gather
+        // overflowed: thousands of pairs share the count at the threshold, and reading every
+        // block that holds one of them would cost gigabytes).  Every block contributes at least
+        // its maximum, so the bound ranked several batches down is a threshold that brings back
+        // enough entries; the third attempt gathers them.
+        if (tid == 0 && attempt < 2) {
+            unsigned long long r = 8ull * (adapt < 16u ? 16u : adapt);     // several batches' worth
+            if (r > kSelCap / 2) r = kSelCap / 2;
+            if (n_all > kSelCap) r = (unsigned long long)kSelCap * r / n_all;
+            r = r < 1 ? 1 : r;
+            if (r > n_l - 1) r = n_l - 1;
             ctl->sel_T = sp[r];
+            ctl->sel_retry = 1;
+        }
+        return;
+    }
+    if (n_all > kSelCap) {
+        if (tid == 0 && attempt == 0) {       // overflow: look at the block bounds next
+            ctl->sel_mode = 1;
             ctl->sel_retry = 1;
             ctl->n_sel_retry += 1;
         }
@@ -2625,7 +2664,7 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
                          int n_cus, int n_ranks) {
     if (sel) {
         const int blocks = (n_cus > 0 ? n_cus : 256) * 4;
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < 3; ++attempt) {
             hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target, attempt);
             hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
                                fused_min, (uint32_t)n_ranks, attempt);

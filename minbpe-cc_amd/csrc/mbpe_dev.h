@@ -106,6 +106,8 @@ struct DevCtl {
     uint32_t sel_retry;         // the first gather overflowed: a second one with a higher threshold follows
     uint32_t adapt_limit;       // batch size limit learnt from validation (0: none yet = kBatchMax)
     uint32_t n_sel_retry;       // statistics
+    uint32_t sel_mode;          // 1: the next first gather lists block bounds (to find a threshold), not entries
+    unsigned long long n_sel_blocks;   // blocks read by the gathers (statistics)
 
 };
 
@@ -196,8 +198,8 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
                          int n_cus, int n_ranks);
-// (two gather + pick attempts are enqueued: when the first gather overflows its list -- many equal
-//  counts -- the pick derives a higher threshold from the sample it got and the second attempt runs)
+// (three gather + pick attempts are enqueued: when the first gather overflows its list -- many equal
+//  counts -- the second lists the block bounds to find a threshold and the third gathers with it)
 // small batch: count the deltas and mark the tiles (the rewrite follows validation)
 void launch_scan_batch(hipStream_t s, const uint16_t *tok0, const uint16_t *tok1, const TileSum *sums,
                        uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,

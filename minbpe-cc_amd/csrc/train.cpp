@@ -1027,6 +1027,9 @@ int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
     c->stats.cut_full = c->begun ? c->h_ctl.cut_full : 0;
     c->stats.n_validation_drops = c->begun ? c->h_ctl.n_validation_drops : 0;
     c->stats.n_sel_fallback = c->begun ? c->h_ctl.n_sel_fallback : 0;
+    c->stats.n_sel_retry = c->begun ? c->h_ctl.n_sel_retry : 0;
+    c->stats.adapt_limit = c->begun ? c->h_ctl.adapt_limit : 0;
+    c->stats.n_sel_blocks = c->begun ? c->h_ctl.n_sel_blocks : 0;
     *out = c->stats;
     return MBPE_OK;
 }

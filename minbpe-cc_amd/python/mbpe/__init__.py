@@ -46,6 +46,7 @@ class Stats(ctypes.Structure):
         ("n_validation_drops", ctypes.c_uint32), ("ms_grow_table", ctypes.c_float), ("ms_compact", ctypes.c_float),
         ("n_table_grows", ctypes.c_uint32), ("n_sel_fallback", ctypes.c_uint32),
         ("fused_launches", ctypes.c_uint32), ("ms_fused_kernel", ctypes.c_float), ("fused_slots", ctypes.c_uint64),
+        ("n_sel_retry", ctypes.c_uint32), ("adapt_limit", ctypes.c_uint32), ("n_sel_blocks", ctypes.c_uint64),
     ]
 
     def as_dict(self):
