@@ -1281,8 +1281,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
             bs->key[accepted] = key;
             bs->eidx[accepted] = cand_idx;
             bs->packed[accepted] = cand;
-            bs->max_l[accepted] = 0;
-            bs->max_r[accepted] = 0;
+            bs->maxp[accepted] = 0;
             best[k0 + accepted] = cand;
         }
         ++accepted;
@@ -1493,8 +1492,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 bs->key[accepted] = key;
                 bs->eidx[accepted] = si[k];
                 bs->packed[accepted] = cand;
-                bs->max_l[accepted] = 0;
-                bs->max_r[accepted] = 0;
+                bs->maxp[accepted] = 0;
                 best[k0 + accepted] = cand;
             }
             ++accepted;
@@ -1938,7 +1936,24 @@ __global__ __launch_bounds__(kMergeThreads, 6) void k_fused_batch(uint16_t *tok0
     if (lane == 0 && wave_rm) atomicAdd(&ctl->rm, wave_rm);
 }
 
-// largest entry of every L_j / R_j (after the all-reduce in a multi-GPU run)
+// Validation (after the all-reduce in a multi-GPU run).  Merge j creates the pairs (x, X_j) with
+// count L_j[x], (X_j, y) with count R_j[y] and (X_p, X_j) with count ADJ[p][j]; while only a prefix
+// of the batch is merged, a match of j that touches a match of a later pair p still has p's plain
+// token as its neighbour, which can add up to adj_in[j] / adj_out[j] to an L / R count.  Pair j of
+// the batch is the reference's next choice iff its packed (count, ~key) -- ties resolved by key,
+// exactly like the argmax -- beats every pair the merges before it can have created.
+
+__global__ void k_adj_sums(const uint32_t *__restrict__ hdr_adj, BatchState *bs, const DevCtl *ctl) {
+    const uint32_t n = ctl->batch_n, j = threadIdx.x;
+    if (n < 2 || j >= (uint32_t)kBatchMax) return;
+    uint32_t in = 0, out = 0;
+    if (j < n)
+        for (uint32_t p = 0; p < n; ++p) { in += hdr_adj[p * kBatchMax + j]; out += hdr_adj[j * kBatchMax + p]; }
+    bs->adj_in[j] = in;
+    bs->adj_out[j] = out;
+}
+
+// per pair j: the largest packed value among the pairs (x, X_j), (X_j, y) it creates
 __global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, const DevCtl *ctl) {
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2) return;
@@ -1947,59 +1962,49 @@ __global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, con
     // the stride is a multiple of kBatchMax, so a thread only ever sees one pair index j
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = (uint32_t)(gid % kBatchMax);
-    uint32_t ml = 0, mr = 0;
-    if (j < n_keys)
-        for (uint64_t i = gid; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-            const uint2 lr = reinterpret_cast<const uint2 *>(LR)[i];
-            ml = lr.x > ml ? lr.x : ml;
-            mr = lr.y > mr ? lr.y : mr;
+    if (j >= n_keys) return;
+    const uint32_t in = bs->adj_in[j], out = bs->adj_out[j], Xj = X + j;
+    unsigned long long mp = 0;
+    for (uint64_t i = gid; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 lr = reinterpret_cast<const uint2 *>(LR)[i];
+        const uint32_t x = (uint32_t)(i / kBatchMax);
+        if (lr.x) {
+            const unsigned long long p = pack_best((int32_t)(lr.x + in), (x << 16) | Xj);
+            mp = p > mp ? p : mp;
         }
-    // lanes l, l + kBatchMax, ... share j
-    for (int d = 32; d >= kBatchMax; d >>= 1) {
-        const uint32_t ol = __shfl_xor(ml, d, kWave), orr = __shfl_xor(mr, d, kWave);
-        ml = ol > ml ? ol : ml;
-        mr = orr > mr ? orr : mr;
+        if (lr.y) {
+            const unsigned long long p = pack_best((int32_t)(lr.y + out), (Xj << 16) | x);
+            mp = p > mp ? p : mp;
+        }
     }
-    if (lane_id() < (uint32_t)kBatchMax && j < n_keys) {
-        if (ml) atomicMax(&bs->max_l[j], ml);
-        if (mr) atomicMax(&bs->max_r[j], mr);
-    }
+    if (mp) atomicMax(&bs->maxp[j], mp);
 }
 
-// How many pairs of the batch the sequential algorithm would really have
-// chosen in this order: pair j stays iff its count beats every pair the
-// merges before it can have created.  Then the deltas of the surviving prefix
-// are made exact for "only the prefix is merged", and the argmax bounds of the
-// dropped pairs are restored.
+// How many pairs of the batch the sequential algorithm would really have chosen in this order
+// (see above).  Then the deltas of the surviving prefix are made exact for "only the prefix is
+// merged", and the argmax bounds of the dropped pairs are restored.
 __global__ __launch_bounds__(256) void k_validate(PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m,
                                                   uint32_t *hdr_adj, uint32_t *LR) {
     static_assert(kBatchMax <= 256, "one workgroup of 256 threads validates a batch");
-    __shared__ uint32_t s_part[256 / kWave];
     __shared__ unsigned long long s_run[256];
     __shared__ uint32_t s_commit;
     const uint32_t tid = threadIdx.x;
     const uint32_t n = ctl->batch_n;
     if (n < 2) return;
-    uint32_t v = 0;
-    for (uint32_t i = tid; i < n * (uint32_t)kBatchMax; i += blockDim.x) {
-        const uint32_t w = hdr_adj[i];
-        v = w > v ? w : v;
-    }
-    v = wave_max_u32(v);
-    if (lane_id() == 0) s_part[tid / kWave] = v;
+    const uint32_t X0 = 256u + ctl->k_done;
+    s_run[tid] = tid < n ? bs->maxp[tid] : 0ull;
     if (tid == 0) s_commit = n;
     __syncthreads();
-    uint32_t max_adj = 0;
-    for (uint32_t w = 0; w < 256 / kWave; ++w) max_adj = s_part[w] > max_adj ? s_part[w] : max_adj;
-    // u_j = upper bound of the count of any pair merge j creates; pair j survives iff its
-    // count beats max(u_0 .. u_{j-1}) (ties go to the safe side)
-    unsigned long long u = 0;
-    if (tid < n) {
-        const unsigned long long l = (unsigned long long)bs->max_l[tid] + max_adj;
-        const unsigned long long r = (unsigned long long)bs->max_r[tid] + max_adj;
-        u = l > r ? l : r;
+    // pairs that only exist through touching matches
+    for (uint32_t i = tid; i < n * (uint32_t)kBatchMax; i += blockDim.x) {
+        const uint32_t p = i / kBatchMax, q = i % kBatchMax;
+        const uint32_t w = hdr_adj[i];
+        if (!w || q >= n) continue;
+        const uint32_t bp = bs->key[p] & 0xFFFFu, aq = bs->key[q] >> 16;
+        atomicMax(&s_run[p > q ? p : q], pack_best((int32_t)w, ((X0 + p) << 16) | (X0 + q)));   // (X_p, X_q)
+        atomicMax(&s_run[q], pack_best((int32_t)bs->adj_in[q], (bp << 16) | (X0 + q)));          // (b_p, X_q), p not merged
+        atomicMax(&s_run[p], pack_best((int32_t)bs->adj_out[p], ((X0 + p) << 16) | aq));         // (X_p, a_q), q not merged
     }
-    s_run[tid] = u;
     __syncthreads();
     for (uint32_t d = 1; d < 256; d <<= 1) {        // inclusive prefix maximum
         const unsigned long long o = tid >= d ? s_run[tid - d] : 0ull;
@@ -2007,7 +2012,7 @@ __global__ __launch_bounds__(256) void k_validate(PairTable t, DevCtl *ctl, Batc
         if (o > s_run[tid]) s_run[tid] = o;
         __syncthreads();
     }
-    if (tid >= 1 && tid < n && (bs->packed[tid] >> 32) <= s_run[tid - 1]) atomicMin(&s_commit, tid);
+    if (tid >= 1 && tid < n && bs->packed[tid] <= s_run[tid - 1]) atomicMin(&s_commit, tid);
     __syncthreads();
     const uint32_t commit = s_commit;
     // a match of a kept pair that touches a match of a dropped pair keeps its plain neighbour
@@ -2753,6 +2758,7 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     uint32_t blocks = (uint32_t)((cells + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 2) blocks = 2;
+    hipLaunchKernelGGL(k_adj_sums, dim3(1), dim3(kBatchMax), 0, s, hdr_adj, bs, ctl);
     hipLaunchKernelGGL(k_delta_max, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, LR, bs, ctl);
     hipLaunchKernelGGL(k_validate, dim3(1), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     if (t.cells) {

@@ -125,8 +125,9 @@ struct BatchState {
     uint32_t key[kBatchMax];      // (first << 16) | second
     uint32_t eidx[kBatchMax];     // entry index in the pair table
     unsigned long long packed[kBatchMax];   // (count << 32) | ~key, as in best[]
-    uint32_t max_l[kBatchMax];    // max_x L_j[x]  (k_delta_max)
-    uint32_t max_r[kBatchMax];    // max_y R_j[y]
+    unsigned long long maxp[kBatchMax];     // largest packed (count, ~key) of the pairs merge j creates (k_delta_max)
+    uint32_t adj_in[kBatchMax];   // sum_p ADJ[p][j]: matches of j directly after another match of the batch
+    uint32_t adj_out[kBatchMax];  // sum_q ADJ[j][q]
 };
 
 // exchange buffer (u32 words): [single-merge header: m, adj, RankEdge x n_ranks]
