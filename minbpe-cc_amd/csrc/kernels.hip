@@ -1405,7 +1405,16 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         if (tid == 0) { ctl->batch_n = 0; ctl->commit_n = 0; ctl->fused = 0; }
         return;
     }
-    if (T == 0ull || n_all == 0) return;        // not primed / nothing above T: the walking kernel takes over
+    if (T == 0ull || n_all == 0) {
+        // not primed, or nothing at or above T: look for a threshold among the bounds of all blocks
+        // that hold a pair with a count (if that finds nothing either, the walking kernel takes over)
+        if (tid == 0 && attempt == 0 && !bounds_only) {
+            ctl->sel_T = 1ull << 32;
+            ctl->sel_mode = 1;
+            ctl->sel_retry = 1;
+        }
+        return;
+    }
     const uint32_t n_l = n_all < kSelCap ? n_all : kSelCap;
     uint32_t n_sort = 64;                       // power of two >= n_l
     while (n_sort < n_l) n_sort <<= 1;
