@@ -1852,10 +1852,10 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
     return pack8(out);
 }
 
-// (6 waves per SIMD: what the 24 KB lookup table in LDS allows; the cold instantiation meets it with two
-//  spilled registers, which is cheaper than running with 5 waves)
+// (7 waves per SIMD: the cold instantiation meets it with two spilled registers, which is cheaper than
+//  running with 6 waves; 8 would spill ten and is slower)
 template <bool CHUNKED, bool HOT, int DIAG = 0>
-__global__ __launch_bounds__(kMergeThreads, 6) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
+__global__ __launch_bounds__(kMergeThreads, 7) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
                                                                const TileSum *__restrict__ sin,
                                                                TileSum *__restrict__ sout, uint32_t n_tiles,
                                                                uint32_t *__restrict__ chg, const BatchState *bs,
