@@ -2,9 +2,13 @@
 //
 // Reference path replaced (code/include/ of justinhj/minbpe-cc):
 //   calculate_freqs            Tokenizer.h:127-146   -> k_pair_count_u8 (+ k_table_init)
-//   get_top_pair_count         PairCount.h:262-269   -> k_argmax
+//   get_top_pair_count         PairCount.h:262-269   -> k_sel_scan + k_sel_pick / k_select_batch
+//                                                       (k_argmax / k_argmax_hier for one merge at a time)
 //   merge_chunks / merge_incremental
-//                              Tokenizer.h:309-320, :202-306 -> k_merge + k_apply
+//                              Tokenizer.h:309-320, :202-306 -> k_fused_batch (large batches),
+//                                                       k_scan_batch + k_rewrite_marked (small ones),
+//                                                       k_merge (one pair); count updates:
+//                                                       k_validate + k_apply_batch[_dense] / k_apply
 //   create_lists / text_to_vector
 //                              Tokenizer.h:114-124, :85-100 -> k_widen
 //
@@ -1074,7 +1078,8 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 }
 
 // ---- batched merges -----------------------------------------------------------------
-// Several merges per pass over the stream.  k_select_batch takes the next
+// Several merges per pass over the stream.  The selection (k_sel_pick, or
+// k_select_batch when the gathered list cannot be used) takes the next
 // candidates in argmax order as long as each one is INDEPENDENT of the ones
 // before it: for an earlier (a,b) and a later (c,d): d != a and c != b (then
 // merging (a,b) cannot change count(c,d), and occurrences of the two pairs
@@ -1082,12 +1087,14 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 // All pairs ranked before a candidate are in the batch, every other old pair
 // can only have lost count, so the candidate is the true next argmax unless a
 // pair created by the earlier merges of the batch ((x,X_i), (X_i,y), (X_p,X_i))
-// beats it.  That is checked exactly-or-conservatively AFTER the counting pass
-// (k_validate) and BEFORE anything is rewritten: the scan pass (k_scan_batch)
-// only counts deltas per pair and marks the tiles that hold matches; the
-// rewrite pass (k_rewrite_marked) then applies the validated prefix to the
-// marked tiles.  A batch of one pair (always valid) takes the fused single
-// pass k_merge instead.
+// beats it.  That is checked AFTER the counting pass (k_validate, comparing
+// packed (count, ~key) values) and BEFORE the stream is changed for good: the
+// scan pass (k_scan_batch) only counts deltas per pair and marks the tiles that
+// hold matches, and the rewrite pass (k_rewrite_marked) then applies the
+// validated prefix to the marked tiles; the fused pass of a large batch
+// (k_fused_batch) writes the merged stream to the other token buffer, which
+// only becomes the stream if the whole batch survives.  A batch of one pair
+// (always valid) takes the in-place pass k_merge instead.
 
 // Lookup table of a batch in LDS: is (first, second) one of the batch pairs, and
 // which one?  A hash table of kBuckets buckets of two keys each, keys stored as
