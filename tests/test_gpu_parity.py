@@ -360,6 +360,30 @@ def test_train_golden_fused_pass(tr, name):
     assert stats["n_live"] == meta["final_len"]
 
 
+@pytest.mark.parametrize("chunked", [False, True])
+def test_tie_heavy_text_large_vocab(tr, chunked):
+    """A text repeated 16 times, trained far into the region where thousands of pairs share a count:
+    candidate lists overflow (threshold found among the block bounds), new pairs tie with the
+    candidates (validation has to compare keys), batch sizes adapt.  Merges, counts, final stream and
+    pair table against the oracle."""
+    base = read_data("shakespeare.txt")[:150000]
+    data = (base + b"\n") * 16
+    off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data) if chunked else None
+    vocab = 256 + (2500 if chunked else 4000)
+    want_m, want_c = O.train(data, vocab, off)
+    m, c, st = tr.train_lexical(data, vocab, off)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+    ost = O.State(data, off)
+    for i, (a, b) in enumerate(want_m):
+        ost.merge(int(a), int(b), 256 + i)
+    toks, _ = tr.stream()
+    assert np.array_equal(toks, ost.stream()[0])
+    assert {k: v for k, v in tr.pairs_dict().items() if v} == {k: v for k, v in ost.table_dict().items() if v}
+    ost.close()
+    assert st["n_batches"] < len(m) // 4          # several merges per pass even here
+    assert st["n_sel_retry"] > 0                  # the overflow -> block bounds -> gather path was taken
+
+
 def test_large_corpus_properties(tr):
     """256 MiB of SplitMix64 bytes, 600 merges (tens of stream passes, compaction, table growth):
     size-independent properties instead of an oracle run --
