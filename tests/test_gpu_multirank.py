@@ -145,6 +145,14 @@ def test_text_three_ranks():
     _check(data, [65536, 131073], 256 + 64)
 
 
+def test_tie_heavy_text_three_ranks():
+    # repeated text trained into the region of many equal counts: key-aware validation and the
+    # selection's overflow path must take the same decisions on every rank
+    base = read_data("shakespeare.txt")[:40000]
+    data = (base + b"\n") * 8
+    _check(data, [len(data) // 3 + 5, 2 * len(data) // 3 - 7], 256 + 900)
+
+
 def test_rccl_single_rank_communicator():
     # A 1-rank RCCL communicator through the production transport: exercises the
     # run-time RCCL binding, ncclCommInitRank and the per-merge ncclAllReduce on
