@@ -153,6 +153,26 @@ def test_tie_heavy_text_three_ranks():
     _check(data, [len(data) // 3 + 5, 2 * len(data) // 3 - 7], 256 + 900)
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_sharded(seed):
+    # random corpora (small alphabets, repeated blocks, runs), random cuts, 2-4 ranks
+    rng = np.random.default_rng(4200 + seed)
+    for _ in range(6):
+        n = int(rng.integers(20, 30000))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            data = rng.integers(97, 97 + int(rng.choice([2, 4, 26])), size=n, dtype=np.uint8)
+        elif kind == 1:
+            blk = rng.integers(97, 110, size=int(rng.integers(3, 200)), dtype=np.uint8)
+            data = np.tile(blk, n // len(blk) + 1)[:n]
+        else:
+            vals = rng.integers(97, 100, size=max(n // 20, 1), dtype=np.uint8)
+            data = np.repeat(vals, rng.integers(1, 60, size=len(vals)))[:n]
+        R = int(rng.integers(2, 5))
+        cuts = sorted(set(int(x) for x in rng.integers(1, len(data), size=R - 1)))
+        _check(data.tobytes(), cuts, 256 + int(rng.integers(5, 120)))
+
+
 def test_rccl_single_rank_communicator():
     # A 1-rank RCCL communicator through the production transport: exercises the
     # run-time RCCL binding, ncclCommInitRank and the per-merge ncclAllReduce on
