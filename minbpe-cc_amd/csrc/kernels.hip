@@ -131,7 +131,7 @@ __device__ __forceinline__ void dc_flush(DeltaCache &dc, uint32_t *LR) {
 }
 
 // is the largest pair of the pass frequent enough for hot count cells?  (one occurrence per
-// 8192 live tokens of this shard)
+// 8192 live tokens; counts are global, so n_live is this shard's live tokens times the ranks)
 __device__ __forceinline__ bool dc_wanted(unsigned long long top_count, unsigned long long n_live) {
     return top_count * 8192ull >= n_live;
 }
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
     const uint32_t key = ~(uint32_t)best;
     const uint32_t a = rfl(key >> 16), b = rfl(key & 0xFFFFu);
     // two instantiations are launched: the one with the delta cache only works on a frequent pair
-    if (dc_wanted(best >> 32, ctl->n_live) != HOT) return;
+    if (dc_wanted(best >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;
     constexpr bool dc_on = HOT;
     if (dc_on) { dc_init(dc); __syncthreads(); }
 
@@ -1666,7 +1666,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2 || ctl->fused) return;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
-    if (dc_wanted(bs->packed[0] >> 32, ctl->n_live) != HOT) return;     // (see k_merge)
+    if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
     lut_build(lut, bs, n_keys);
@@ -1879,7 +1879,7 @@ __global__ __launch_bounds__(kMergeThreads, 7) void k_fused_batch(uint16_t *tok0
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     uint16_t *dst = ctl->cur ? tok0 : tok1;
     const uint32_t X0 = 256u + ctl->k_done;
-    if (dc_wanted(bs->packed[0] >> 32, ctl->n_live) != HOT) return;     // (see k_merge)
+    if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
     lut_build(lut, bs, n_keys);

@@ -107,6 +107,7 @@ struct DevCtl {
     uint32_t adapt_limit;       // batch size limit learnt from validation (0: none yet = kBatchMax)
     uint32_t n_sel_retry;       // statistics
     uint32_t sel_mode;          // 1: the next first gather lists block bounds (to find a threshold), not entries
+    uint32_t n_ranks;           // shards of the stream (1 without multi-GPU); set at begin
     unsigned long long n_sel_blocks;   // blocks read by the gathers (statistics)
 
 };

@@ -579,6 +579,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     {
         DevCtl init = {};
         init.n_live = n;         // every corpus byte starts as one live token
+        init.n_ranks = (uint32_t)std::max(1, c->n_ranks);
         c->h_ctl = init;
         HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl, sizeof(DevCtl), hipMemcpyHostToDevice, c->stream));
     }
