@@ -148,11 +148,19 @@ __device__ __forceinline__ uint32_t hash_key(uint32_t k) {
 // insert it with count = delta.  Within one kernel no two threads ever insert
 // the same key (see k_apply / k_table_init), so a found key always has its
 // entry index published by an earlier kernel.
+// Dense layout: tiles of 32 first tokens x 32 second tokens (1024 cells = 4 KB = one block of the
+// argmax bounds), tiles row-major.  32 consecutive second tokens of a row are contiguous, and the
+// same column of 32 consecutive rows stays inside one 4 KB tile, so that the one scattered update
+// of a batch -- (x, a_j) for all x -- reuses DRAM pages instead of opening one per update.
 __device__ __forceinline__ uint32_t dense_index(const PairTable &t, uint32_t key) {
-    return ((key >> 16) << t.vshift) | (key & 0xFFFFu);
+    const uint32_t f = key >> 16, g = key & 0xFFFFu;
+    return ((((f >> 5) << (t.vshift - 5u)) | (g >> 5)) << 10) | ((f & 31u) << 5) | (g & 31u);
 }
 __device__ __forceinline__ uint32_t dense_key(const PairTable &t, uint32_t e) {
-    return ((e >> t.vshift) << 16) | (e & ((1u << t.vshift) - 1u));
+    const uint32_t tile = e >> 10, w = e & 1023u;
+    const uint32_t f = ((tile >> (t.vshift - 5u)) << 5) | (w >> 5);
+    const uint32_t g = ((tile & ((1u << (t.vshift - 5u)) - 1u)) << 5) | (w & 31u);
+    return (f << 16) | g;
 }
 
 // entries the argmax has to look at
@@ -1335,6 +1343,7 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
     // Blocks are dealt out round robin (block B belongs to wave B mod n_waves): the blocks above
     // the threshold are usually neighbours (the same few first tokens), and a wave reads its blocks
     // one after the other.  The price is that the 64 bounds a wave looks at per step are strided.
+    uint32_t blocks_read = 0;
     for (uint64_t step = 0; step * n_waves * kWave < n_blocks; ++step) {
         // far more entries than the list holds: no point in reading on, k_sel_pick will look for a
         // better threshold among the block bounds
@@ -1382,12 +1391,11 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
                 }
             }
             mx = wave_max_u64(mx);
-            if (lane == 0) {
-                __hip_atomic_store(&t.bmax[blk], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(&ctl->n_sel_blocks, 1ull);
-            }
+            if (lane == 0) __hip_atomic_store(&t.bmax[blk], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++blocks_read;
         }
     }
+    if (lane == 0 && blocks_read) atomicAdd(&ctl->n_sel_blocks, (unsigned long long)blocks_read);
 }
 
 constexpr int kPickThreads = 1024;
@@ -2106,38 +2114,33 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
 
 // The same for the dense pair table, arranged so that three of the four updates per delta are
 // contiguous.  A workgroup takes 64 ids x and 64 pairs j through LDS:
-//   lanes along j:  (x, a_j) -= L   (scattered over row x)     (x, X_j)  = L   (64 consecutive cells of row x)
-//   lanes along x:  (b_j, x) -= R   (64 consecutive cells of row b_j)   (X_j, x) = R   (... of row X_j)
+//   lanes along j:  (x, a_j) -= L   (scattered over row x)     (x, X_j)  = L   (64 neighbouring cells of row x)
+//   lanes along x:  (b_j, x) -= R   (64 neighbouring cells of row b_j)   (X_j, x) = R   (... of row X_j)
+// (neighbouring = runs of 32 contiguous cells in the tiled layout)
 // A new token's pairs are plain stores; their argmax bounds are raised once per wave.
 constexpr int kApplyTile = 64;
 
-__device__ __forceinline__ void dense_insert_run(const PairTable &t, DevCtl *ctl, bool active, uint32_t e,
-                                                 uint32_t key, uint32_t count) {
-    // lanes hold consecutive cells e (same row); active lanes insert count
+__device__ __forceinline__ void dense_insert_run(const PairTable &t, bool active, uint32_t e, uint32_t key,
+                                                 uint32_t count, uint32_t &n_new) {
+    // lanes hold neighbouring cells e of one row (one to three tiles); active lanes insert count;
+    // n_new (uniform) collects the number of inserts -- one atomic on ctl->n_entries per wave, not per
+    // call: that counter is a single address
     if (active) t.cells[e] = kPresent | count;
-    const unsigned long long m = __ballot(active);
+    unsigned long long m = __ballot(active);
     if (!m) return;
-    unsigned long long p = active ? pack_best((int32_t)count, key) : 0ull;
+    n_new += (uint32_t)__popcll(m);
+    const unsigned long long p = active ? pack_best((int32_t)count, key) : 0ull;
     const uint32_t blk = e >> kBlockShift;
-    const uint32_t blk0 = rfl(__shfl(blk, (uint32_t)__builtin_ctzll(m), kWave));
-    if (__ballot(active && blk != blk0) == 0ull) {       // one bound block (the usual case)
-        p = wave_max_u64(p);
+    while (m) {                                   // one bound update per tile touched
+        const uint32_t blk0 = rfl(__shfl(blk, (uint32_t)__builtin_ctzll(m), kWave));
+        const bool mine = active && blk == blk0;
+        const unsigned long long pm = wave_max_u64(mine ? p : 0ull);
         if (lane_id() == 0) {
-            atomicAdd(&ctl->n_entries, (uint32_t)__popcll(m));
-            if (p > t.bmax[blk0]) atomicMax(&t.bmax[blk0], p);
-            if (p > t.smax[blk0 >> kBlockShift]) atomicMax(&t.smax[blk0 >> kBlockShift], p);
+            if (pm > t.bmax[blk0]) atomicMax(&t.bmax[blk0], pm);
+            if (pm > t.smax[blk0 >> kBlockShift]) atomicMax(&t.smax[blk0 >> kBlockShift], pm);
         }
-    } else if (active) {
-        atomicAdd(&ctl->n_entries, 1u);
-        if (p > t.bmax[blk]) atomicMax(&t.bmax[blk], p);
-        if (p > t.smax[blk >> kBlockShift]) atomicMax(&t.smax[blk >> kBlockShift], p);
+        m &= ~__ballot(mine);
     }
-}
-
-__device__ __forceinline__ void dense_decrement(const PairTable &t, DevCtl *ctl, uint32_t e, uint32_t by) {
-    const uint32_t old = atomicAdd(&t.cells[e], 0u - by);
-    if (!(old & kPresent)) atomicOr(&ctl->err, kErrMissingPair);
-    else if ((old & ~kPresent) < by) atomicOr(&ctl->err, kErrNegCount);
 }
 
 __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *ctl, const BatchState *bs,
@@ -2164,24 +2167,53 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
             tile[r][lane] = lr;
         }
         __syncthreads();
-        const uint32_t pitch_shift = t.vshift;
+        // The decrements return the old value (an absent pair or a negative count is an error worth
+        // knowing about); four of them are in flight per lane before the first one is looked at.
+        constexpr uint32_t kRows = kApplyTile / (256 / kWave);        // rows (columns) per wave: 16
+        uint32_t err = 0, n_new = 0;
         // lanes along j: left neighbours x
-        for (uint32_t r = wave; r < (uint32_t)kApplyTile; r += 256 / kWave) {
-            const uint32_t x = x0 + r, j = j0 + lane;
-            const uint32_t l = tile[r][lane].x;
-            const uint32_t a = j < n ? bs->key[j] >> 16 : 0u;
-            if (l) dense_decrement(t, ctl, (x << pitch_shift) | a, l);
-            dense_insert_run(t, ctl, l != 0u, (x << pitch_shift) | (X0 + j), (x << 16) | (X0 + j), l);
+        const uint32_t jl = j0 + lane;
+        const uint32_t a = jl < n ? bs->key[jl] >> 16 : 0u;
+        for (uint32_t r0 = 0; r0 < kRows; r0 += 4) {
+            uint32_t l[4], old[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t r = wave + (r0 + u) * (256 / kWave), x = x0 + r;
+                l[u] = tile[r][lane].x;
+                old[u] = kPresent | l[u];
+                if (l[u]) old[u] = atomicAdd(&t.cells[dense_index(t, (x << 16) | a)], 0u - l[u]);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t r = wave + (r0 + u) * (256 / kWave), x = x0 + r;
+                dense_insert_run(t, l[u] != 0u, dense_index(t, (x << 16) | (X0 + jl)), (x << 16) | (X0 + jl), l[u], n_new);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                err |= !(old[u] & kPresent) ? kErrMissingPair : ((old[u] & ~kPresent) < l[u] ? kErrNegCount : 0u);
         }
         // lanes along x: right neighbours x
-        for (uint32_t c = wave; c < (uint32_t)kApplyTile; c += 256 / kWave) {
-            const uint32_t x = x0 + lane, j = j0 + c;
-            if (j >= n) break;
-            const uint32_t rr = tile[lane][c].y;
-            const uint32_t b = bs->key[j] & 0xFFFFu, X = X0 + j;
-            if (rr) dense_decrement(t, ctl, (b << pitch_shift) | x, rr);
-            dense_insert_run(t, ctl, rr != 0u, (X << pitch_shift) | x, (X << 16) | x, rr);
+        const uint32_t xr = x0 + lane;
+        for (uint32_t c0 = 0; c0 < kRows; c0 += 4) {
+            uint32_t rr[4], old[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t c = wave + (c0 + u) * (256 / kWave), j = j0 + c;
+                rr[u] = j < n ? tile[lane][c].y : 0u;
+                old[u] = kPresent | rr[u];
+                if (rr[u]) old[u] = atomicAdd(&t.cells[dense_index(t, ((bs->key[j] & 0xFFFFu) << 16) | xr)], 0u - rr[u]);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t c = wave + (c0 + u) * (256 / kWave), X = X0 + j0 + c;
+                dense_insert_run(t, rr[u] != 0u, dense_index(t, (X << 16) | xr), (X << 16) | xr, rr[u], n_new);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                err |= !(old[u] & kPresent) ? kErrMissingPair : ((old[u] & ~kPresent) < rr[u] ? kErrNegCount : 0u);
         }
+        if (err) atomicOr(&ctl->err, err);
+        if (lane == 0 && n_new) atomicAdd(&ctl->n_entries, n_new);
     }
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < (uint64_t)kBatchMax * kBatchMax) {

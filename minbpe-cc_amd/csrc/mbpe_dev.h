@@ -56,10 +56,11 @@ constexpr int kBlockShift = 10;                 // argmax hierarchy: 1024 entrie
 constexpr uint32_t kBlockSize = 1u << kBlockShift;   // 1024 blocks per super-block
 
 // Pair table, two layouts behind the same device functions (table_add, entry_packed):
-//  * dense (cells != NULL; vocab <= 32,768): one u32 per possible pair, cell index
-//    e = (first << vshift) | second, value = kPresent | count for a pair that was ever
-//    inserted, 0 otherwise.  No hashing, no growth; inserts of a new token's pairs and
-//    updates along a row are contiguous.  ecap = number of cells = 1 << (2 * vshift).
+//  * dense (cells != NULL; vocab <= 32,768): one u32 per possible pair, stored as tiles of
+//    32 x 32 (first, second) cells (see dense_index in kernels.hip), value = kPresent | count
+//    for a pair that was ever inserted, 0 otherwise.  No hashing, no growth; inserts of a new
+//    token's pairs and updates along a row come in contiguous runs.  ecap = number of cells
+//    = 1 << (2 * vshift), vshift = log2 of the vocabulary rounded up to a power of two (>= 256).
 //  * hashed (larger vocabularies): open addressing over appended entries.
 // "Entry index" below means the cell index (dense) or the append index (hashed).
 struct PairTable {

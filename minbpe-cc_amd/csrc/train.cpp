@@ -1085,20 +1085,29 @@ int mbpe_get_pairs(mbpe_ctx *c, uint32_t *first_out, uint32_t *second_out, int32
     if (!first_out) return MBPE_OK;
     if (cap < n) { mbpe_host::set_last_error("pair arrays too small"); return MBPE_ERR_ARG; }
     if (c->tab.cells) {
-        // dense layout: the rows of the ids that exist, one at a time (row-major = key order)
+        // dense layout: 32 x 32 tiles, row-major; copy the tile rows that hold ids that exist
         const uint32_t pitch = 1u << c->tab.vshift, ids = std::min<uint32_t>(256 + c->k, pitch);
-        std::vector<uint32_t> row(pitch);
-        uint64_t o = 0;
-        for (uint32_t f = 0; f < ids; ++f) {
-            HIPCHK(hipMemcpy(row.data(), c->tab.cells + (size_t)f * pitch, (size_t)ids * 4, hipMemcpyDeviceToHost));
-            for (uint32_t sec = 0; sec < ids; ++sec) {
-                if (!(row[sec] & kPresent)) continue;
-                if (o >= n) { mbpe_host::set_last_error("pair table holds more pairs than counted"); return MBPE_ERR_OVERFLOW; }
-                first_out[o] = f;
-                second_out[o] = sec;
-                if (count_out) count_out[o] = (int32_t)(row[sec] & ~kPresent);
-                ++o;
-            }
+        const uint32_t tpr = pitch / 32, used_tiles = (ids + 31) / 32;
+        std::vector<uint32_t> rowbuf((size_t)used_tiles * 1024);
+        struct Rec { uint32_t f, s; int32_t c; };
+        std::vector<Rec> recs;
+        recs.reserve(n);
+        for (uint32_t tr = 0; tr < used_tiles; ++tr) {
+            HIPCHK(hipMemcpy(rowbuf.data(), c->tab.cells + (size_t)tr * tpr * 1024, rowbuf.size() * 4,
+                             hipMemcpyDeviceToHost));
+            for (uint32_t fr = 0; fr < 32; ++fr)
+                for (uint32_t tc = 0; tc < used_tiles; ++tc)
+                    for (uint32_t sc = 0; sc < 32; ++sc) {
+                        const uint32_t v = rowbuf[(size_t)tc * 1024 + fr * 32 + sc];
+                        if (v & kPresent) recs.push_back({tr * 32 + fr, tc * 32 + sc, (int32_t)(v & ~kPresent)});
+                    }
+        }
+        uint64_t o = recs.size();
+        if (o > n) { mbpe_host::set_last_error("pair table holds more pairs than counted"); return MBPE_ERR_OVERFLOW; }
+        for (uint64_t i = 0; i < o; ++i) {
+            first_out[i] = recs[i].f;
+            second_out[i] = recs[i].s;
+            if (count_out) count_out[i] = recs[i].c;
         }
         if (o != n) { mbpe_host::set_last_error("pair table holds fewer pairs than counted"); return MBPE_ERR_OVERFLOW; }
         return MBPE_OK;
