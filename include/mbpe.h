@@ -178,7 +178,7 @@ MBPE_API int mbpe_get_pairs(mbpe_ctx *ctx, uint32_t *first_out, uint32_t *second
 MBPE_API int mbpe_compact(mbpe_ctx *ctx);
 
 /* Tuning knobs (tests force rare paths with them).
- *   "compact_den"   compact when holes * den >= slots (default 8; 0 = never)
+ *   "compact_den"   compact when holes * den >= slots (default 16; 0 = never)
  *   "batch"         sequences (or single merges) per host round trip (default 64)
  *   "multi_merge"   1 = several independent merges per stream pass (default), 0 = one
  *   "max_batch"     most merges one pass may take (default and limit 128)

@@ -173,7 +173,7 @@ struct mbpe_ctx {
     uint32_t pending_target = 0;          // external mode: merge count the pending call runs up to
 
     // options
-    int64_t opt_compact_den = 8;
+    int64_t opt_compact_den = 16;
     int64_t opt_batch = 64;
     int64_t opt_use_graph = 1;
     int64_t opt_time_kernels = 0;   // HIP events around every merge kernel (bench.py)

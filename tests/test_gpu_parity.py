@@ -116,7 +116,7 @@ def test_train_tiny_inputs(tr, data, vocab):
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
-DEFAULTS = {"compact_den": 8, "batch": 64, "multi_merge": 1, "max_batch": 1024, "fused_min": 24, "hier_argmax": -1,
+DEFAULTS = {"compact_den": 16, "batch": 64, "multi_merge": 1, "max_batch": 1024, "fused_min": 24, "hier_argmax": -1,
             "dense_table": -1, "threshold_select": 1}
 
 
@@ -213,7 +213,7 @@ def test_train_options_do_not_change_results(tr, batch, den):
         m, c, st = tr.train_lexical(data, 400)
     finally:
         tr.set_option("batch", 64)
-        tr.set_option("compact_den", 8)
+        tr.set_option("compact_den", 16)
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
     if den == 1:
         assert st["n_compactions"] > 0
@@ -397,7 +397,7 @@ def test_large_corpus_properties(tr):
     try:
         m, c, st = tr.train_lexical(data, 256 + 600)
     finally:
-        tr.set_option("compact_den", 8)
+        tr.set_option("compact_den", 16)
     assert len(m) == 600 and np.all(np.diff(c) <= 0)
     table = O.pair_count_u8(data)
     first = int(np.argmax(table))                      # ties resolve to the smallest key, like the trainer
