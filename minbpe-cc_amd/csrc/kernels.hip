@@ -1868,9 +1868,9 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
 }
 
 // (7 waves per SIMD: the cold instantiation meets it with two spilled registers, which is cheaper than
-//  running with 6 waves; 8 would spill ten and is slower)
+//  running with 6 waves; 8 would spill ten and is slower.  The delta cache of the HOT one allows 5.)
 template <bool CHUNKED, bool HOT, int DIAG = 0>
-__global__ __launch_bounds__(kMergeThreads, 7) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
+__global__ __launch_bounds__(kMergeThreads, HOT ? 5 : 7) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
                                                                const TileSum *__restrict__ sin,
                                                                TileSum *__restrict__ sout, uint32_t n_tiles,
                                                                uint32_t *__restrict__ chg, const BatchState *bs,
