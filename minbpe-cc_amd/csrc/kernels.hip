@@ -1462,8 +1462,8 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         // its maximum, so the bound ranked several batches down is a threshold that brings back
         // enough entries; the third attempt gathers them.
         if (tid == 0 && attempt < 2) {
-            unsigned long long r = 8ull * (adapt < 16u ? 16u : adapt);     // several batches' worth
-            if (r > kSelCap / 2) r = kSelCap / 2;
+            unsigned long long r = 2ull * (adapt < 32u ? 32u : adapt);     // blocks; each holds >= 1 entry, often several
+            if (r > kSelCap / 4) r = kSelCap / 4;
             if (n_all > kSelCap) r = (unsigned long long)kSelCap * r / n_all;
             r = r < 1 ? 1 : r;
             if (r > n_l - 1) r = n_l - 1;
