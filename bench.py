@@ -107,8 +107,8 @@ def main():
     ap.add_argument("--bytes", type=int, default=4 << 30, help="corpus bytes (whole job)")
     ap.add_argument("--vocab", type=int, default=32000)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--cpu-sample-mib", type=int, default=64)
-    ap.add_argument("--cpu-merges", type=int, default=24)
+    ap.add_argument("--cpu-sample-mib", type=int, default=256)
+    ap.add_argument("--cpu-merges", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
