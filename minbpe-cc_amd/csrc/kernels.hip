@@ -535,19 +535,109 @@ __device__ Halo halo_slow(const TileSum *sin, uint32_t n_tiles, uint32_t tile, c
     return h;
 }
 
-// number of tokens equal to raw `a` immediately before `tile` (a == b merges)
-__device__ unsigned long long run_before_slow(const TileSum *sin, uint32_t tile, uint32_t a, const RankEdge *le) {
-    unsigned long long rb = 0;
-    int64_t j = (int64_t)tile - 1;
-    for (; j >= 0; --j) {
-        TileSum s = sin[j];
-        if (s.n_live == 0) continue;
-        if (s.tail0 != a) return rb;
-        rb += s.tail_run;
-        if (s.tail_run != s.n_live) return rb;
+// ---- (t,t) merges: how many tokens equal to raw t lie immediately before every tile --------------
+// A merge of (t,t) takes every second token of a run of t, so a tile that starts inside a run has to
+// know the run's length before it (its parity, and whether it is >= 2).  Walking the summaries back
+// from every tile is quadratic in a corpus that is one long run; instead a segmented scan over the
+// tiles (chunks of 4096, like the compaction scan) computes it for all tiles in two small kernels,
+// which run only when the pair to merge is a (t,t).
+//   element of a tile: (len = its trailing run of t, full = the whole tile is t, or empty)
+//   L then R:  R.full ? (L.len + R.len, L.full) : R
+// run_in[tile] = (run & 1) | (run >= 2 ? 2 : 0), with the left rank's trailing run added when
+// everything before the tile is t.
+constexpr int kRunThreads = 256;
+constexpr int kRunPerThread = 16;
+constexpr uint32_t kRunChunk = kRunThreads * kRunPerThread;      // 4096 tiles, as tile_scan_scratch assumes
+
+struct RunSeg { unsigned long long len; bool full; };
+__device__ __forceinline__ RunSeg run_join(RunSeg l, RunSeg r) {
+    RunSeg o;
+    o.len = r.full ? l.len + r.len : r.len;
+    o.full = r.full && l.full;
+    return o;
+}
+__device__ __forceinline__ RunSeg run_seg_of(const TileSum &s, uint32_t t) {
+    RunSeg o;
+    if (s.n_live == 0) { o.len = 0; o.full = true; }
+    else if (s.tail0 != t) { o.len = 0; o.full = false; }
+    else { o.len = s.tail_run; o.full = s.tail_run == s.n_live; }
+    return o;
+}
+__device__ __forceinline__ unsigned long long run_pack(RunSeg r) { return (r.len << 1) | (r.full ? 1ull : 0ull); }
+__device__ __forceinline__ RunSeg run_unpack(unsigned long long v) { RunSeg r; r.len = v >> 1; r.full = v & 1ull; return r; }
+
+// the token of the (t,t) pair about to be merged, or 0xFFFFFFFF when this sequence merges something else
+__device__ __forceinline__ uint32_t run_token(const unsigned long long *best_ptr, const DevCtl *ctl, int seq) {
+    if (seq) {
+        if (ctl->batch_n != 1) return 0xFFFFFFFFu;
+        best_ptr += ctl->k_done;
     }
-    if (le && le->tail0 == a) rb += ((unsigned long long)le->tail_run_hi << 32) | le->tail_run_lo;
-    return rb;
+    const unsigned long long best = *best_ptr;
+    if ((best >> 32) == 0) return 0xFFFFFFFFu;
+    const uint32_t key = ~(uint32_t)best;
+    return (key >> 16) == (key & 0xFFFFu) ? key >> 16 : 0xFFFFFFFFu;
+}
+
+// join of the segments of a thread's kRunPerThread consecutive tiles, then of the workgroup (thread 0)
+__device__ __forceinline__ RunSeg run_chunk_join(const TileSum *sin, uint32_t n_tiles, uint32_t t, uint64_t first,
+                                                 unsigned long long *sh) {
+    RunSeg mine; mine.len = 0; mine.full = true;
+    for (int i = 0; i < kRunPerThread; ++i)
+        if (first + i < n_tiles) mine = run_join(mine, run_seg_of(sin[first + i], t));
+    sh[threadIdx.x] = run_pack(mine);
+    __syncthreads();
+    return mine;
+}
+
+__global__ __launch_bounds__(kRunThreads) void k_run_partial(const TileSum *__restrict__ sin, uint32_t n_tiles,
+                                                             const unsigned long long *best_ptr, const DevCtl *ctl,
+                                                             int seq, unsigned long long *__restrict__ part) {
+    __shared__ unsigned long long sh[kRunThreads];
+    const uint32_t t = run_token(best_ptr, ctl, seq);
+    if (t == 0xFFFFFFFFu) return;
+    const uint64_t first = (uint64_t)blockIdx.x * kRunChunk + (uint64_t)threadIdx.x * kRunPerThread;
+    run_chunk_join(sin, n_tiles, t, first, sh);
+    if (threadIdx.x == 0) {
+        RunSeg acc; acc.len = 0; acc.full = true;
+        for (int i = 0; i < kRunThreads; ++i) acc = run_join(acc, run_unpack(sh[i]));
+        part[blockIdx.x] = run_pack(acc);
+    }
+}
+
+__global__ __launch_bounds__(kRunThreads) void k_run_final(const TileSum *__restrict__ sin, uint32_t n_tiles,
+                                                           const unsigned long long *best_ptr, const DevCtl *ctl,
+                                                           int seq, const unsigned long long *__restrict__ part,
+                                                           const RankEdge *le, uint32_t *__restrict__ run_in) {
+    __shared__ unsigned long long sh[kRunThreads];
+    __shared__ unsigned long long pre[kRunThreads];
+    const uint32_t t = run_token(best_ptr, ctl, seq);
+    if (t == 0xFFFFFFFFu) return;
+    // everything before this chunk: each thread joins a slice of the chunk aggregates, thread 0 the slices
+    const uint32_t nb = blockIdx.x, per = (nb + kRunThreads - 1) / kRunThreads;
+    RunSeg acc; acc.len = 0; acc.full = true;
+    for (uint32_t i = threadIdx.x * per; i < nb && i < (threadIdx.x + 1) * per; ++i) acc = run_join(acc, run_unpack(part[i]));
+    pre[threadIdx.x] = run_pack(acc);
+    const uint64_t first = (uint64_t)blockIdx.x * kRunChunk + (uint64_t)threadIdx.x * kRunPerThread;
+    run_chunk_join(sin, n_tiles, t, first, sh);            // (syncs)
+    if (threadIdx.x == 0) {
+        RunSeg run; run.len = 0; run.full = true;
+        for (int i = 0; i < kRunThreads; ++i) run = run_join(run, run_unpack(pre[i]));
+        for (int i = 0; i < kRunThreads; ++i) {            // exclusive scan over the threads of this chunk
+            const RunSeg mine = run_unpack(sh[i]);
+            sh[i] = run_pack(run);
+            run = run_join(run, mine);
+        }
+    }
+    __syncthreads();
+    RunSeg run = run_unpack(sh[threadIdx.x]);
+    const unsigned long long edge =
+        le && le->tail0 == t ? ((unsigned long long)le->tail_run_hi << 32) | le->tail_run_lo : 0ull;
+    for (int i = 0; i < kRunPerThread; ++i) {
+        if (first + i >= n_tiles) break;
+        const unsigned long long rb = run.len + (run.full ? edge : 0ull);
+        run_in[first + i] = (uint32_t)(rb & 1ull) | (rb >= 2 ? 2u : 0u);
+        run = run_join(run, run_seg_of(sin[first + i], t));
+    }
 }
 
 __global__ __launch_bounds__(kMergeThreads) void k_summarize(const uint16_t *__restrict__ tok,
@@ -770,7 +860,7 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
                                                 uint32_t n_tiles,
                                              uint32_t tile, uint32_t s[8], const Halo h, uint32_t a, uint32_t b,
                                              uint32_t X, uint32_t *LR, DeltaCache &dc, bool dc_on,
-                                             const RankEdge *le,
+                                             const uint32_t *run_in,
                                              uint32_t &wave_m, uint32_t &wave_adj, uint32_t &wave_rm) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
@@ -844,9 +934,7 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
         uint32_t ea = __shfl_up(sa, 1, kWave), et = __shfl_up(st, 1, kWave);
         if (lane == 0) { ea = 1; et = 0; }
         // lanes with ea set: the run reaches back to the start of the tile
-        unsigned long long rb = 0;
-        if (__ballot(ea && cnt > 0) != 0ull && h.p1 == a) rb = run_before_slow(sin, tile, a, le);
-        const uint32_t rb_small = (uint32_t)(rb & 1ull) | (rb >= 2 ? 2u : 0u);
+        const uint32_t rb_small = run_in[tile];      // run of a before this tile: parity and ">= 2" (k_run_final)
         run = ea ? et + rb_small : et;   // parity and ">= 2" are all that is used below
     }
 
@@ -911,7 +999,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
                                                          const unsigned long long *__restrict__ best_ptr,
                                                          uint32_t X, uint32_t *LR, DevCtl *ctl,
                                                          uint32_t *m_adj, const RankEdge *le,
-                                                         const RankEdge *re, int seq) {
+                                                         const RankEdge *re, int seq,
+                                                         const uint32_t *__restrict__ run_in) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     __shared__ DeltaCache dc;
     const uint32_t lane = lane_id();
@@ -988,8 +1077,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
             }
             bool work = __ballot(acc == 0u) != 0ull || h.p1 == a;
             if (DIAG == 2) { asm volatile("" :: "v"(acc)); work = false; }
-            if (work) merge_tile_full<CHUNKED>(tok, sin, sout, chg, n_tiles, tile, s, h, a, b, X, LR, dc, dc_on, le, wave_m,
-                                                   wave_adj, wave_rm);
+            if (work) merge_tile_full<CHUNKED>(tok, sin, sout, chg, n_tiles, tile, s, h, a, b, X, LR, dc, dc_on, run_in,
+                                                   wave_m, wave_adj, wave_rm);
         }
 
         if (!v1) break;
@@ -2660,34 +2749,40 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileSum *sin, TileSum *sout, uint32_t n_tiles,
                   uint32_t *chg, const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *LR,
                   DevCtl *ctl, uint32_t *m_adj, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus,
-                  int seq) {
+                  int seq, unsigned long long *run_part, uint32_t *run_in) {
     if (!n_tiles) return;
+    {   // runs of t before every tile, for a (t,t) pair (the kernels return at once for any other pair)
+        const uint32_t n_chunks = (n_tiles + kRunChunk - 1) / kRunChunk;
+        hipLaunchKernelGGL(k_run_partial, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, run_part);
+        hipLaunchKernelGGL(k_run_final, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, run_part,
+                           left_edge, run_in);
+    }
     static const int occ_c = resident_blocks(k_merge<true, false, 0>), occ_b = resident_blocks(k_merge<false, false, 0>);
     const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_MERGE_DIAG") ? atoi(getenv("MBPE_MERGE_DIAG")) : 0;
     if (diag == 1 && !endbit) {
         hipLaunchKernelGGL((k_merge<false, false, 1>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq);
+                           m_adj, left_edge, right_edge, seq, run_in);
         return;
     }
     if (diag == 2 && !endbit) {
         hipLaunchKernelGGL((k_merge<false, false, 2>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq);
+                           m_adj, left_edge, right_edge, seq, run_in);
         return;
     }
 #endif
     // (both instantiations: each returns at once unless the pair's frequency is its case)
     if (endbit) {
         hipLaunchKernelGGL((k_merge<true, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq);
+                           m_adj, left_edge, right_edge, seq, run_in);
         hipLaunchKernelGGL((k_merge<true, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq);
+                           m_adj, left_edge, right_edge, seq, run_in);
     } else {
         hipLaunchKernelGGL((k_merge<false, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq);
+                           m_adj, left_edge, right_edge, seq, run_in);
         hipLaunchKernelGGL((k_merge<false, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq);
+                           m_adj, left_edge, right_edge, seq, run_in);
     }
 }
 

@@ -181,7 +181,9 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileSum *sums, TileSum *side,
                   uint32_t n_tiles, uint32_t *chg, const unsigned long long *best, uint32_t new_id,
                   uint32_t endbit, uint32_t *LR, DevCtl *ctl, uint32_t *m_adj /* [m, adj] accumulators */,
-                  const RankEdge *left_edge, const RankEdge *right_edge, int n_cus, int seq);
+                  const RankEdge *left_edge, const RankEdge *right_edge, int n_cus, int seq,
+                  unsigned long long *run_part /* tile_scan_scratch(n_tiles) entries */,
+                  uint32_t *run_in /* n_tiles entries: run of t before every tile, for (t,t) pairs */);
 // seq != 0: the kernel runs inside a batch sequence: it reads the merge index
 // from ctl->k_done and returns at once unless the selected batch has one pair;
 // tok / tok_other are then token buffers 0 / 1 and ctl->cur picks the live one

@@ -634,7 +634,8 @@ static void step_local(mbpe_ctx *c, int ev_slot) {
     const bool multi = is_multi(c);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     launch_merge(c->stream, c->tok[c->cur], c->tok[1 - c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best + c->k, X, endbit, c->LR,
-                 c->ctl, &c->ctl->m, multi ? c->d_left : nullptr, multi ? c->d_right : nullptr, c->n_cus, 0);
+                 c->ctl, &c->ctl->m, multi ? c->d_left : nullptr, multi ? c->d_right : nullptr, c->n_cus, 0,
+                 c->offsets + c->n_tiles, c->tile_list);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
     if (multi) {
         launch_patch_sums(c->stream, c->best + c->k, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 0);
@@ -675,7 +676,7 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     // (the live token buffer is ctl->cur: a fused pass flips it without the host knowing)
     launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
-                 multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1);
+                 multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1, c->offsets + c->n_tiles, c->tile_list);
     launch_scan_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
                       c->ctl, le, re, endbit, c->n_cus);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev_f[2 * ev_slot], c->stream);

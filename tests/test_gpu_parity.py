@@ -384,6 +384,28 @@ def test_tie_heavy_text_large_vocab(tr, chunked):
     assert st["n_sel_retry"] > 0                  # the overflow -> block bounds -> gather path was taken
 
 
+def test_one_giant_run(tr):
+    """16 MiB of one byte: every merge is a (t,t) merge over a run that spans all 32,768 tiles (the
+    run length before every tile comes from a segmented scan, not from walking the summaries back;
+    1 GiB takes 0.06 s)."""
+    data = np.full(16 << 20, 97, dtype=np.uint8)
+    want_m, want_c = O.train(data, 256 + 24)
+    m, c, st = tr.train_lexical(data, 256 + 24)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+    ost = O.State(data)
+    for i, (a, b) in enumerate(want_m):
+        ost.merge(int(a), int(b), 256 + i)
+    assert np.array_equal(tr.stream()[0], ost.stream()[0])
+    ost.close()
+    # runs interrupted at odd places, across many tiles
+    rng = np.random.default_rng(3)
+    data = np.full(8 << 20, 97, dtype=np.uint8)
+    data[rng.integers(0, len(data), size=40)] = 98
+    want_m, want_c = O.train(data, 256 + 30)
+    m, c, _ = tr.train_lexical(data, 256 + 30)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
 def test_large_corpus_properties(tr):
     """256 MiB of SplitMix64 bytes, 600 merges (tens of stream passes, compaction, table growth):
     size-independent properties instead of an oracle run --
