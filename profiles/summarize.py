@@ -2,7 +2,7 @@
 """Condenses rocprofv3 CSV output (kernel_stats / counter_collection) into the
 small per-kernel summaries committed under profiles/.
 
-usage: summarize.py stats <kernel_stats.csv> | pmc <counter_collection.csv>
+usage: summarize.py stats <kernel_stats.csv> | trace <kernel_trace.csv> | pmc <counter_collection.csv>
 PMC note (guide: /opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE and
 WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced read, so the corrected read traffic is 2 x FETCH_SIZE x 1024.
@@ -27,6 +27,19 @@ def main():
             print("%s,%s,%.3f,%.2f,%.2f,%.2f,%s" % (k, r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
                                                      float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    elif mode == "trace":
+        # per-dispatch durations: every sequence launches all of its kernels and the device decides
+        # which of them work, so most dispatches return at once; "working" = at least 20 us
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            if k:
+                agg[k].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+        print("kernel,dispatches,total_ms,working,working_total_ms,working_avg_us,working_max_us")
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w = [x for x in v if x >= 20.0]
+            print("%s,%d,%.3f,%d,%.3f,%.2f,%.2f" % (k, len(v), sum(v) / 1e3, len(w), sum(w) / 1e3,
+                                                  sum(w) / max(len(w), 1), max(v)))
     else:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(path)):
