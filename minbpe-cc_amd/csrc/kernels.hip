@@ -1776,12 +1776,11 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
     TileIn t0 = tile_issue(tok, sums_rsrc, tile);
     TileIn t1 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + n_waves));
-    TileIn t2 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 2ull * n_waves));
-    bool v1 = (uint64_t)tile + n_waves < n_tiles, v2 = (uint64_t)tile + 2ull * n_waves < n_tiles;
+    bool v1 = (uint64_t)tile + n_waves < n_tiles;
     const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
     for (;;) {
-        const bool v3 = (uint64_t)tile + 3ull * n_waves < n_tiles;
-        TileIn t3 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 3ull * n_waves));
+        const bool v2 = (uint64_t)tile + 2ull * n_waves < n_tiles;
+        TileIn t2 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 2ull * n_waves));
 
         const uint32_t me_nlive = rlane(t0.smw, 6) & 0xFFFFu;
         if (DIAG == 1) {
@@ -1824,8 +1823,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
         }
         if (!v1) break;
         tile += n_waves;
-        t0 = t1; t1 = t2; t2 = t3;
-        v1 = v2; v2 = v3;
+        t0 = t1; t1 = t2;
+        v1 = v2;
     }
     }
     if (dc_on) dc_flush(dc, LR);
