@@ -7,9 +7,12 @@
 #include "mbpe_host.h"
 
 #include <dlfcn.h>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -21,6 +24,7 @@ constexpr uint32_t kPCRE2_UTF          = 0x00080000u;
 constexpr uint32_t kPCRE2_NO_UTF_CHECK = 0x40000000u;
 constexpr uint32_t kPCRE2_JIT_COMPLETE = 0x00000001u;
 constexpr int      kPCRE2_ERROR_NOMATCH = -1;
+constexpr uint32_t kPCRE2_INFO_MAXLOOKBEHIND = 15;
 
 struct Pcre2Api {
     void *lib = nullptr;
@@ -32,6 +36,7 @@ struct Pcre2Api {
     int (*match)(const void *, const uint8_t *, size_t, size_t, uint32_t, void *, void *) = nullptr;
     size_t *(*get_ovector_pointer)(void *) = nullptr;
     int (*get_error_message)(int, uint8_t *, size_t) = nullptr;
+    int (*pattern_info)(const void *, uint32_t, void *) = nullptr;
     bool ok = false;
     std::string why;
 };
@@ -58,6 +63,7 @@ Pcre2Api &pcre2() {
         MBPE_BIND(match, "pcre2_match_8")
         MBPE_BIND(get_ovector_pointer, "pcre2_get_ovector_pointer_8")
         MBPE_BIND(get_error_message, "pcre2_get_error_message_8")
+        MBPE_BIND(pattern_info, "pcre2_pattern_info_8")
 #undef MBPE_BIND
         api.ok = true;
     });
@@ -108,7 +114,33 @@ int Splitter::compile(const std::string &pattern, std::string *err) {
 
 // The match loop of Tokenizer::train / encode, Tokenizer.h:506-540 and :676-703:
 // every non-empty match [start,end) is a chunk; an empty match advances the
-// offset by one byte; NOMATCH ends the loop.
+// offset by one byte; NOMATCH ends the loop.  Runs from `offset` until the offset
+// reaches `stop` (n for the whole text); `offset` is left where the loop stood.
+// Returns MBPE_OK, or 1 when NOMATCH ended the loop (no further match to the end of the text).
+static int match_loop(const void *code, void *match_data, const uint8_t *text, uint64_t n, size_t &offset,
+                      uint64_t stop, std::vector<uint64_t> *starts, std::vector<uint64_t> *ends, std::string *err) {
+    Pcre2Api &p = pcre2();
+    while (offset < stop || stop == n) {
+        int rc = p.match(code, text, n, offset, kPCRE2_NO_UTF_CHECK, match_data, nullptr);
+        if (rc < 0) {
+            if (rc == kPCRE2_ERROR_NOMATCH) return 1;
+            *err = "PCRE2 match error: " + pcre2_message(rc);            // :517-522
+            return MBPE_ERR_REGEX;
+        }
+        size_t *ov = p.get_ovector_pointer(match_data);
+        size_t start = ov[0], end = ov[1];
+        if (start == end) {                                              // :529-533
+            if (offset >= n) return 1;
+            offset++;
+            continue;
+        }
+        starts->push_back(start);
+        ends->push_back(end);
+        offset = end;
+    }
+    return MBPE_OK;
+}
+
 int Splitter::split(const uint8_t *text, uint64_t n, std::vector<uint64_t> *starts,
                     std::vector<uint64_t> *ends, std::string *err) const {
     starts->clear();
@@ -121,24 +153,103 @@ int Splitter::split(const uint8_t *text, uint64_t n, std::vector<uint64_t> *star
     Pcre2Api &p = pcre2();
     static const uint8_t kEmpty[1] = {0};
     if (!text) text = kEmpty;      // std::string::data() of an empty string is never NULL
-    size_t offset = 0;
-    for (;;) {
-        int rc = p.match(code_, text, n, offset, kPCRE2_NO_UTF_CHECK, match_data_, nullptr);
-        if (rc < 0) {
-            if (rc == kPCRE2_ERROR_NOMATCH) break;
-            *err = "PCRE2 match error: " + pcre2_message(rc);            // :517-522
-            return MBPE_ERR_REGEX;
+
+    // Large texts are split by several host threads.  A match attempt at offset o depends only on
+    // the text from o on when the pattern looks behind nowhere (PCRE2_INFO_MAXLOOKBEHIND == 0:
+    // true of the gpt2 / gpt4 patterns), so the sequential loop of the reference is a walk over
+    // offsets whose continuation is determined by the current offset alone.  Thread k runs the loop
+    // from a guessed offset S_k; the true walk, stitched sequentially, takes over thread k's matches
+    // from the first offset both have visited (normally a handful of matches after S_k), and keeps
+    // matching on its own until then.  The result is the sequential one, match for match.
+    uint32_t lookbehind = 1;
+    if (p.pattern_info(code_, kPCRE2_INFO_MAXLOOKBEHIND, &lookbehind) != 0) lookbehind = 1;
+    unsigned n_threads = 1;
+    if (lookbehind == 0 && n >= (8u << 20)) {
+        unsigned hw = std::thread::hardware_concurrency();
+        const char *env = getenv("MBPE_SPLIT_THREADS");
+        unsigned want = env ? (unsigned)atoi(env) : 16u;
+        n_threads = std::max(1u, std::min({want, hw ? hw : 1u, (unsigned)(n >> 20)}));
+    }
+    if (n_threads <= 1) {
+        size_t offset = 0;
+        int rc = match_loop(code_, match_data_, text, n, offset, n, starts, ends, err);
+        return rc < 0 ? rc : MBPE_OK;
+    }
+
+    struct Part {
+        uint64_t s0 = 0;                       // guessed start offset (a character boundary)
+        std::vector<uint64_t> starts, ends;
+        size_t final_offset = 0;
+        bool no_more = false;                  // NOMATCH: nothing matches from final_offset to the end
+        int rc = MBPE_OK;
+        std::string err;
+    };
+    std::vector<Part> parts(n_threads);
+    for (unsigned k = 0; k < n_threads; ++k) {
+        uint64_t s0 = (uint64_t)k * n / n_threads;
+        while (s0 < n && (text[s0] & 0xC0) == 0x80) ++s0;     // not inside a UTF-8 sequence
+        parts[k].s0 = s0;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned k = 0; k < n_threads; ++k) {
+        pool.emplace_back([&, k] {
+            Part &pt = parts[k];
+            void *md = k == 0 ? match_data_ : p.match_data_create_from_pattern(code_, nullptr);
+            if (!md) { pt.rc = MBPE_ERR_REGEX; pt.err = "PCRE2 match data creation failed."; return; }
+            const uint64_t stop = k + 1 < n_threads ? parts[k + 1].s0 : n;
+            size_t offset = pt.s0;
+            pt.starts.reserve((stop - pt.s0) / 3);
+            pt.ends.reserve((stop - pt.s0) / 3);
+            int rc = match_loop(code_, md, text, n, offset, stop, &pt.starts, &pt.ends, &pt.err);
+            if (rc < 0) pt.rc = rc;
+            pt.no_more = rc == 1;
+            pt.final_offset = offset;
+            if (k != 0) p.match_data_free(md);
+        });
+    }
+    for (auto &t : pool) t.join();
+    for (const Part &pt : parts)
+        if (pt.rc != MBPE_OK) { *err = pt.err; return pt.rc; }
+
+    // stitch: `cur` is the offset of the true walk
+    starts->swap(parts[0].starts);
+    ends->swap(parts[0].ends);
+    size_t cur = parts[0].final_offset;
+    bool done = parts[0].no_more;
+    for (unsigned k = 1; k < n_threads && !done; ++k) {
+        Part &pt = parts[k];
+        const uint64_t region_end = k + 1 < n_threads ? parts[k + 1].s0 : n;
+        for (;;) {
+            // has thread k stood at offset cur?  (its start, or the end of one of its matches)
+            size_t from = SIZE_MAX;
+            if (cur == pt.s0) from = 0;
+            else {
+                auto it = std::lower_bound(pt.ends.begin(), pt.ends.end(), (uint64_t)cur);
+                if (it != pt.ends.end() && *it == cur) from = (size_t)(it - pt.ends.begin()) + 1;
+            }
+            if (from != SIZE_MAX) {
+                starts->insert(starts->end(), pt.starts.begin() + from, pt.starts.end());
+                ends->insert(ends->end(), pt.ends.begin() + from, pt.ends.end());
+                cur = pt.final_offset;
+                done = pt.no_more;
+                break;
+            }
+            if (cur >= region_end) break;      // walked through the whole region without meeting thread k
+            // one more step of the true walk
+            size_t before = ends->size();
+            size_t off = cur;
+            int rc = match_loop(code_, match_data_, text, n, off, std::min<uint64_t>(cur + 1, n), starts, ends, err);
+            if (rc < 0) return rc;
+            if (rc == 1) { done = true; break; }
+            (void)before;
+            cur = off;
         }
-        size_t *ov = p.get_ovector_pointer(match_data_);
-        size_t start = ov[0], end = ov[1];
-        if (start == end) {                                              // :529-533
-            if (offset >= n) break;
-            offset++;
-            continue;
-        }
-        starts->push_back(start);
-        ends->push_back(end);
-        offset = end;
+    }
+    if (!done && cur < n) {
+        // (only when the last region never met the true walk)
+        size_t off = cur;
+        int rc = match_loop(code_, match_data_, text, n, off, n, starts, ends, err);
+        if (rc < 0) return rc;
     }
     return MBPE_OK;
 }

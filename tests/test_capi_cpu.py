@@ -71,3 +71,26 @@ def test_presplit_bad_pattern():
     with pytest.raises(mbpe.MbpeError) as e:
         mbpe.presplit("(unclosed", b"abc")
     assert e.value.code == mbpe.ERR_REGEX
+
+
+@pytest.mark.parametrize("enc", ["gpt2", "gpt4"])
+def test_presplit_parallel_equals_sequential(enc, monkeypatch):
+    """Texts of 8 MiB and more are split by several host threads (each from a guessed offset, stitched
+    to the sequential walk): the chunk offsets must be those of the single-threaded loop exactly --
+    ASCII text, text with multi-byte characters (sample.txt has emoji), long whitespace runs."""
+    import mbpe
+    from conftest import read_data
+    pattern = mbpe.split_pattern(enc)
+    texts = [
+        (read_data("shakespeare.txt") + b"\n") * 9,
+        (read_data("sample.txt") + b" \r\n\t  ") * 400,
+        (b"word " * 1000 + b" " * 70000 + b"\n" * 3000 + "\u00e9\u4e2d\U0001F600 x1234567 ".encode()) * 120,
+    ]
+    for text in texts:
+        assert len(text) >= (8 << 20)
+        monkeypatch.setenv("MBPE_SPLIT_THREADS", "1")
+        want = mbpe.presplit(pattern, text)
+        for threads in ("2", "3", "7", "16"):
+            monkeypatch.setenv("MBPE_SPLIT_THREADS", threads)
+            got = mbpe.presplit(pattern, text)
+            assert np.array_equal(got, want), (enc, threads, len(text))
