@@ -211,9 +211,13 @@ int Splitter::split(const uint8_t *text, uint64_t n, std::vector<uint64_t> *star
     for (const Part &pt : parts)
         if (pt.rc != MBPE_OK) { *err = pt.err; return pt.rc; }
 
-    // stitch: `cur` is the offset of the true walk
-    starts->swap(parts[0].starts);
-    ends->swap(parts[0].ends);
+    // stitch: `cur` is the offset of the true walk.  The result is a list of segments (a range of a
+    // thread's matches, or a few matches the true walk made on its own between two threads),
+    // copied into place by the threads afterwards.
+    struct Seg { const std::vector<uint64_t> *s, *e; size_t from, to; };
+    std::vector<Seg> segs;
+    std::vector<std::vector<uint64_t>> bridge_s(n_threads), bridge_e(n_threads);
+    segs.push_back({&parts[0].starts, &parts[0].ends, 0, parts[0].starts.size()});
     size_t cur = parts[0].final_offset;
     bool done = parts[0].no_more;
     for (unsigned k = 1; k < n_threads && !done; ++k) {
@@ -228,29 +232,49 @@ int Splitter::split(const uint8_t *text, uint64_t n, std::vector<uint64_t> *star
                 if (it != pt.ends.end() && *it == cur) from = (size_t)(it - pt.ends.begin()) + 1;
             }
             if (from != SIZE_MAX) {
-                starts->insert(starts->end(), pt.starts.begin() + from, pt.starts.end());
-                ends->insert(ends->end(), pt.ends.begin() + from, pt.ends.end());
+                segs.push_back({&pt.starts, &pt.ends, from, pt.starts.size()});
                 cur = pt.final_offset;
                 done = pt.no_more;
                 break;
             }
             if (cur >= region_end) break;      // walked through the whole region without meeting thread k
             // one more step of the true walk
-            size_t before = ends->size();
             size_t off = cur;
-            int rc = match_loop(code_, match_data_, text, n, off, std::min<uint64_t>(cur + 1, n), starts, ends, err);
+            int rc = match_loop(code_, match_data_, text, n, off, std::min<uint64_t>(cur + 1, n), &bridge_s[k],
+                                &bridge_e[k], err);
             if (rc < 0) return rc;
             if (rc == 1) { done = true; break; }
-            (void)before;
             cur = off;
         }
+        if (!bridge_s[k].empty()) {
+            // (the bridge precedes the part of thread k that was adopted, if any)
+            Seg b{&bridge_s[k], &bridge_e[k], 0, bridge_s[k].size()};
+            if (segs.back().s == &pt.starts) segs.insert(segs.end() - 1, b);
+            else segs.push_back(b);
+        }
     }
+    std::vector<uint64_t> tail_s, tail_e;
     if (!done && cur < n) {
         // (only when the last region never met the true walk)
         size_t off = cur;
-        int rc = match_loop(code_, match_data_, text, n, off, n, starts, ends, err);
+        int rc = match_loop(code_, match_data_, text, n, off, n, &tail_s, &tail_e, err);
         if (rc < 0) return rc;
+        segs.push_back({&tail_s, &tail_e, 0, tail_s.size()});
     }
+    size_t total = 0;
+    std::vector<size_t> at(segs.size());
+    for (size_t i = 0; i < segs.size(); ++i) { at[i] = total; total += segs[i].to - segs[i].from; }
+    starts->reserve(total + 1);       // (+1: mbpe_presplit appends the end of the text)
+    starts->resize(total);
+    ends->resize(total);
+    std::vector<std::thread> copiers;
+    for (size_t i = 0; i < segs.size(); ++i)
+        copiers.emplace_back([&, i] {
+            const Seg &g = segs[i];
+            std::copy(g.s->begin() + g.from, g.s->begin() + g.to, starts->begin() + at[i]);
+            std::copy(g.e->begin() + g.from, g.e->begin() + g.to, ends->begin() + at[i]);
+        });
+    for (auto &t : copiers) t.join();
     return MBPE_OK;
 }
 
@@ -303,10 +327,10 @@ int mbpe_presplit(const char *pattern, const uint8_t *text, uint64_t n_bytes, mb
         return MBPE_ERR_SPLIT_GAP;
     }
     mbpe_split *s = new mbpe_split();
-    s->off.reserve(starts.size() + 1);
-    for (uint64_t v : starts) s->off.push_back(v);
+    const bool none = starts.empty();
+    s->off.swap(starts);              // chunk c starts where chunk c - 1 ended (checked above)
     s->off.push_back(n_bytes);
-    if (starts.empty()) { s->off.clear(); s->off.push_back(0); }
+    if (none) { s->off.clear(); s->off.push_back(0); }
     *out = s;
     return MBPE_OK;
 }
