@@ -578,12 +578,16 @@ __device__ __forceinline__ uint32_t run_token(const unsigned long long *best_ptr
     return (key >> 16) == (key & 0xFFFFu) ? key >> 16 : 0xFFFFFFFFu;
 }
 
-// join of the segments of a thread's kRunPerThread consecutive tiles, then of the workgroup (thread 0)
-__device__ __forceinline__ RunSeg run_chunk_join(const TileSum *sin, uint32_t n_tiles, uint32_t t, uint64_t first,
-                                                 unsigned long long *sh) {
-    RunSeg mine; mine.len = 0; mine.full = true;
-    for (int i = 0; i < kRunPerThread; ++i)
-        if (first + i < n_tiles) mine = run_join(mine, run_seg_of(sin[first + i], t));
+// The segments of a chunk's 4096 tiles, loaded coalesced into LDS; then every thread joins its
+// kRunPerThread consecutive tiles (result also left in sh[thread]).
+__device__ __forceinline__ RunSeg run_chunk_join(const TileSum *sin, uint32_t n_tiles, uint32_t t, uint64_t base,
+                                                 unsigned long long *segs, unsigned long long *sh) {
+    RunSeg none; none.len = 0; none.full = true;
+    for (uint32_t i = threadIdx.x; i < kRunChunk; i += kRunThreads)
+        segs[i] = run_pack(base + i < n_tiles ? run_seg_of(sin[base + i], t) : none);
+    __syncthreads();
+    RunSeg mine = none;
+    for (int i = 0; i < kRunPerThread; ++i) mine = run_join(mine, run_unpack(segs[threadIdx.x * kRunPerThread + i]));
     sh[threadIdx.x] = run_pack(mine);
     __syncthreads();
     return mine;
@@ -592,11 +596,11 @@ __device__ __forceinline__ RunSeg run_chunk_join(const TileSum *sin, uint32_t n_
 __global__ __launch_bounds__(kRunThreads) void k_run_partial(const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                              const unsigned long long *best_ptr, const DevCtl *ctl,
                                                              int seq, unsigned long long *__restrict__ part) {
+    __shared__ unsigned long long segs[kRunChunk];
     __shared__ unsigned long long sh[kRunThreads];
     const uint32_t t = run_token(best_ptr, ctl, seq);
     if (t == 0xFFFFFFFFu) return;
-    const uint64_t first = (uint64_t)blockIdx.x * kRunChunk + (uint64_t)threadIdx.x * kRunPerThread;
-    run_chunk_join(sin, n_tiles, t, first, sh);
+    run_chunk_join(sin, n_tiles, t, (uint64_t)blockIdx.x * kRunChunk, segs, sh);
     if (threadIdx.x == 0) {
         RunSeg acc; acc.len = 0; acc.full = true;
         for (int i = 0; i < kRunThreads; ++i) acc = run_join(acc, run_unpack(sh[i]));
@@ -608,6 +612,7 @@ __global__ __launch_bounds__(kRunThreads) void k_run_final(const TileSum *__rest
                                                            const unsigned long long *best_ptr, const DevCtl *ctl,
                                                            int seq, const unsigned long long *__restrict__ part,
                                                            const RankEdge *le, uint32_t *__restrict__ run_in) {
+    __shared__ unsigned long long segs[kRunChunk];
     __shared__ unsigned long long sh[kRunThreads];
     __shared__ unsigned long long pre[kRunThreads];
     const uint32_t t = run_token(best_ptr, ctl, seq);
@@ -617,8 +622,8 @@ __global__ __launch_bounds__(kRunThreads) void k_run_final(const TileSum *__rest
     RunSeg acc; acc.len = 0; acc.full = true;
     for (uint32_t i = threadIdx.x * per; i < nb && i < (threadIdx.x + 1) * per; ++i) acc = run_join(acc, run_unpack(part[i]));
     pre[threadIdx.x] = run_pack(acc);
-    const uint64_t first = (uint64_t)blockIdx.x * kRunChunk + (uint64_t)threadIdx.x * kRunPerThread;
-    run_chunk_join(sin, n_tiles, t, first, sh);            // (syncs)
+    const uint64_t base = (uint64_t)blockIdx.x * kRunChunk;
+    run_chunk_join(sin, n_tiles, t, base, segs, sh);            // (syncs)
     if (threadIdx.x == 0) {
         RunSeg run; run.len = 0; run.full = true;
         for (int i = 0; i < kRunThreads; ++i) run = run_join(run, run_unpack(pre[i]));
@@ -632,12 +637,17 @@ __global__ __launch_bounds__(kRunThreads) void k_run_final(const TileSum *__rest
     RunSeg run = run_unpack(sh[threadIdx.x]);
     const unsigned long long edge =
         le && le->tail0 == t ? ((unsigned long long)le->tail_run_hi << 32) | le->tail_run_lo : 0ull;
+    // (the per-tile results go back through LDS so that the stores are coalesced too)
     for (int i = 0; i < kRunPerThread; ++i) {
-        if (first + i >= n_tiles) break;
+        const uint32_t k = threadIdx.x * kRunPerThread + i;
         const unsigned long long rb = run.len + (run.full ? edge : 0ull);
-        run_in[first + i] = (uint32_t)(rb & 1ull) | (rb >= 2 ? 2u : 0u);
-        run = run_join(run, run_seg_of(sin[first + i], t));
+        const RunSeg here = run_unpack(segs[k]);
+        segs[k] = (rb & 1ull) | (rb >= 2 ? 2ull : 0ull);
+        run = run_join(run, here);
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kRunChunk; i += kRunThreads)
+        if (base + i < n_tiles) run_in[base + i] = (uint32_t)segs[i];
 }
 
 __global__ __launch_bounds__(kMergeThreads) void k_summarize(const uint16_t *__restrict__ tok,
