@@ -2464,6 +2464,7 @@ __global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag) {
         else ctl->n_fused_dropped += 1;
     }
     ctl->fused = 0;
+    if (ctl->commit_n) ctl->size_hist[31 - __builtin_clz(ctl->commit_n) > 7 ? 7 : 31 - __builtin_clz(ctl->commit_n)] += 1;
     ctl->k_done += ctl->commit_n;
     ctl->batch_n = 0;
     ctl->commit_n = 0;

@@ -109,6 +109,7 @@ struct DevCtl {
     uint32_t n_sel_retry;       // statistics
     uint32_t sel_mode;          // 1: the next first gather lists block bounds (to find a threshold), not entries
     uint32_t n_ranks;           // shards of the stream (1 without multi-GPU); set at begin
+    uint32_t size_hist[8];      // committed batch sizes: 1, 2-3, 4-7, ..., 128+ (statistics)
     unsigned long long n_sel_blocks;   // blocks read by the gathers (statistics)
 
 };

@@ -1032,6 +1032,7 @@ int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
     c->stats.n_sel_retry = c->begun ? c->h_ctl.n_sel_retry : 0;
     c->stats.adapt_limit = c->begun ? c->h_ctl.adapt_limit : 0;
     c->stats.n_sel_blocks = c->begun ? c->h_ctl.n_sel_blocks : 0;
+    for (int i = 0; i < 8; ++i) c->stats.size_hist[i] = c->begun ? c->h_ctl.size_hist[i] : 0;
     *out = c->stats;
     return MBPE_OK;
 }

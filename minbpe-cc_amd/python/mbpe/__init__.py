@@ -46,11 +46,14 @@ class Stats(ctypes.Structure):
         ("n_validation_drops", ctypes.c_uint32), ("ms_grow_table", ctypes.c_float), ("ms_compact", ctypes.c_float),
         ("n_table_grows", ctypes.c_uint32), ("n_sel_fallback", ctypes.c_uint32),
         ("fused_launches", ctypes.c_uint32), ("ms_fused_kernel", ctypes.c_float), ("fused_slots", ctypes.c_uint64),
-        ("n_sel_retry", ctypes.c_uint32), ("adapt_limit", ctypes.c_uint32), ("n_sel_blocks", ctypes.c_uint64),
+        ("n_sel_retry", ctypes.c_uint32), ("adapt_limit", ctypes.c_uint32), ("n_sel_blocks", ctypes.c_uint64), ("size_hist", ctypes.c_uint32 * 8),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["size_hist"] = list(self.size_hist)
+        return d
+
 
 
 class MbpeError(RuntimeError):
