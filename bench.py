@@ -269,7 +269,7 @@ def main():
                        "pairs": s1["n_pairs"]},
             "batches": {k: s1[k] for k in ("n_batches", "n_fused", "n_fused_dropped", "cut_conflict", "cut_bucket",
                                            "cut_single", "cut_full", "n_validation_drops", "ms_grow_table", "ms_compact",
-                                           "n_table_grows", "ms_steps", "n_sel_fallback", "n_sel_retry", "size_hist")},
+                                           "n_table_grows", "ms_steps", "n_sel_fallback", "n_sel_retry", "size_hist", "n_skipped", "n_skip_cut")},
             "first_counts": [int(c) for c in counts[:3]],
         }
         if not args.no_cpu_baseline and world == 1:

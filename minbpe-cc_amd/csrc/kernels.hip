@@ -1396,6 +1396,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
             bs->eidx[accepted] = cand_idx;
             bs->packed[accepted] = cand;
             bs->maxp[accepted] = 0;
+            bs->skip_n = 0;                 // (this kernel ends the batch at a dependent pair)
             best[k0 + accepted] = cand;
         }
         ++accepted;
@@ -1561,7 +1562,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         // its maximum, so the bound ranked several batches down is a threshold that brings back
         // enough entries; the third attempt gathers them.
         if (tid == 0 && attempt < 2) {
-            unsigned long long r = 2ull * (adapt < 32u ? 32u : adapt);     // blocks; each holds >= 1 entry, often several
+            unsigned long long r = 3ull * (adapt < 32u ? 32u : adapt);     // blocks; each holds >= 1 entry, often several
             if (r > kSelCap / 4) r = kSelCap / 4;
             if (n_all > kSelCap) r = (unsigned long long)kSelCap * r / n_all;
             r = r < 1 ? 1 : r;
@@ -1591,12 +1592,17 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
 #pragma unroll
         for (int r = 0; r < kPer; ++r) my_a[r] = my_b[r] = my_h[r] = 0xFFFFFFFFu;
         uint32_t cut = 0;      // 1 conflict, 2 bucket, 3 single
-        for (uint32_t k = 0; k < limit && k < n_l; ++k) {
-            const unsigned long long cand = sp[k];
+        uint32_t n_skip = 0, ci = 0;
+        // (on text a dependent pair often does NOT fall behind -- few of its occurrences overlap the
+        //  earlier pair's -- and a failed pass-over costs a stream pass; after a failure dependent
+        //  pairs end the batch again for a while, see k_seq_finish)
+        const bool skip_allowed = ctl->skip_off == 0;
+        for (; accepted < limit && ci < n_l; ++ci) {
+            const unsigned long long cand = sp[ci];
             const uint32_t count = (uint32_t)(cand >> 32), key = ~(uint32_t)cand;
             const uint32_t a = key >> 16, b = key & 0xFFFFu, h = pair_hash(a, b);
             const bool single = count == 0 || a == b;
-            if (k > 0) {
+            if (accepted > 0) {
                 bool c1 = false;
                 uint32_t same_l = 0;
 #pragma unroll
@@ -1606,21 +1612,38 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 }
                 const unsigned long long conf = __ballot(c1);
                 const uint32_t same = wave_sum(same_l);
-                if (single || conf != 0ull || same >= 2) { cut = single ? 3u : (conf ? 1u : 2u); break; }
+                if (single) { cut = 3u; break; }
+                if (conf != 0ull && n_skip < (uint32_t)kSkipMax && skip_allowed) {
+                    // Depends on an earlier member (shares a token with it the wrong way round): the
+                    // earlier merge eats some of its occurrences, so its count will have dropped by the
+                    // time it could be chosen -- normally below the whole batch.  Pass it over;
+                    // k_validate checks from the measured deltas that it really fell behind every
+                    // member chosen after this point, and cuts the batch here otherwise.
+                    if (tid == 0) {
+                        bs->skip_key[n_skip] = key;
+                        bs->skip_pos[n_skip] = accepted;
+                        bs->skip_packed[n_skip] = cand;
+                    }
+                    ++n_skip;
+                    continue;
+                }
+                if (conf != 0ull || same >= 2) { cut = conf ? 1u : 2u; break; }
             }
 #pragma unroll
             for (int r = 0; r < kPer; ++r)
                 if (accepted == (uint32_t)r * kWave + tid) { my_a[r] = a; my_b[r] = b; my_h[r] = h; }
             if (tid == 0) {
                 bs->key[accepted] = key;
-                bs->eidx[accepted] = si[k];
+                bs->eidx[accepted] = si[ci];
                 bs->packed[accepted] = cand;
                 bs->maxp[accepted] = 0;
                 best[k0 + accepted] = cand;
             }
             ++accepted;
-            if (single) { cut = 3u; break; }
+            if (single) { cut = 3u; ++ci; break; }
         }
+        // (candidates passed over behind the last member do not matter: nothing was chosen after them)
+        if (tid == 0) { bs->skip_n = n_skip; ctl->n_skipped += n_skip; }
         if (tid == 0) {
             ctl->batch_n = accepted;
             ctl->commit_n = accepted;
@@ -1634,13 +1657,18 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             if (cut == 0u && accepted == limit) ctl->cut_full += 1;
             // next threshold: about 128 candidates beyond this batch, or a window twice as wide
             // when the list ended before the batch was full
-            const uint32_t want = accepted + 2u * (adapt < 16u ? 16u : adapt);
+            const uint32_t want = ci + 2u * (adapt < 16u ? 16u : adapt);
             if (n_l > want) {
                 ctl->sel_T = sp[want];          // (the full packed value: also cuts inside a run of equal counts)
             } else {
+                // The list did not reach that far: open the window by at least 1/64 of the count (a
+                // short list has a tiny spread, and doubling it batch after batch would take many
+                // passes of a handful of merges each).  Too wide is cheap: the gather stops early and
+                // the block bounds give the threshold.
                 const unsigned long long c_hi = sp[0] >> 32, c_lo = sp[n_l - 1] >> 32;
-                const unsigned long long spread = c_hi - c_lo > 0 ? c_hi - c_lo : 1;
-                ctl->sel_T = c_lo > spread ? (c_lo - spread) << 32 : 0ull;
+                unsigned long long spread = c_hi - c_lo > 0 ? c_hi - c_lo : 1;
+                if (spread < 1 + c_lo / 64) spread = 1 + c_lo / 64;
+                ctl->sel_T = c_lo > spread ? (c_lo - spread) << 32 : 1ull << 32;
             }
         }
     }
@@ -2134,6 +2162,28 @@ __global__ __launch_bounds__(256) void k_validate(PairTable t, DevCtl *ctl, Batc
         __syncthreads();
     }
     if (tid >= 1 && tid < n && bs->packed[tid] <= s_run[tid - 1]) atomicMin(&s_commit, tid);
+    // candidates the selection passed over because an earlier member eats some of their occurrences:
+    // (c, a_i) loses L_i[c], (b_i, d) loses R_i[d].  With those measured, the candidate must rank below
+    // every member chosen after it; the batch ends at the first member it still beats.
+    if (tid < bs->skip_n) {
+        const uint32_t pos = bs->skip_pos[tid], key = bs->skip_key[tid];
+        const uint32_t c = key >> 16, d = key & 0xFFFFu;
+        unsigned long long red = 0;
+        for (uint32_t i = 0; i < pos && i < n; ++i) {
+            const uint32_t ai = bs->key[i] >> 16, bi = bs->key[i] & 0xFFFFu;
+            if (d == ai) red += LR[lr_idx(c, i, 0)];
+            if (c == bi) red += LR[lr_idx(d, i, 1)];
+        }
+        const unsigned long long cnt0 = bs->skip_packed[tid] >> 32;
+        const unsigned long long later = pack_best((int32_t)(cnt0 > red ? cnt0 - red : 0ull), key);
+        for (uint32_t m = pos; m < n; ++m)
+            if (bs->packed[m] < later) {
+                atomicMin(&s_commit, m);
+                atomicAdd(&ctl->n_skip_cut, 1u);
+                ctl->skip_failed = 1;
+                break;
+            }
+    }
     __syncthreads();
     const uint32_t commit = s_commit;
     // a match of a kept pair that touches a match of a dropped pair keeps its plain neighbour
@@ -2441,8 +2491,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *tok0
 }
 
 // last kernel of a sequence: advance the merge counter
-__global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag) {
+__global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag, const BatchState *bs) {
     if (blockIdx.x || threadIdx.x) return;
+    const uint32_t bs_skip_n = bs->skip_n;
     if (fused_flag) *fused_flag = ctl->fused && ctl->batch_n >= 2 ? 1u : 0u;
     if (ctl->batch_n >= 2) {       // (a single-pair batch was accounted by k_apply)
         const uint32_t rm = ctl->rm;
@@ -2458,6 +2509,16 @@ __global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag) {
         else if (ctl->batch_n >= lim) lim = lim * 2u;
         ctl->adapt_limit = lim > (uint32_t)kBatchMax ? (uint32_t)kBatchMax : lim;
     }
+    // passing over dependent candidates: back off after a failure, recover after successes
+    if (ctl->skip_off) ctl->skip_off -= 1;
+    if (ctl->batch_n >= 2 && ctl->skip_failed) {
+        const uint32_t pen = ctl->skip_penalty ? (ctl->skip_penalty * 2u > 256u ? 256u : ctl->skip_penalty * 2u) : 8u;
+        ctl->skip_penalty = pen;
+        ctl->skip_off = pen;
+    } else if (ctl->batch_n >= 2 && bs_skip_n > 0 && ctl->skip_penalty) {
+        ctl->skip_penalty /= 2u;
+    }
+    ctl->skip_failed = 0;
     if (ctl->fused && ctl->batch_n >= 2) {
         ctl->n_fused += 1;
         if (ctl->commit_n == ctl->batch_n) ctl->cur ^= 1u;   // the fused pass's output becomes the stream
@@ -2938,8 +2999,8 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok, uint16_t *tok1, const T
                            left_edge, right_edge);
 }
 
-void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag) {
-    hipLaunchKernelGGL(k_seq_finish, dim3(1), dim3(64), 0, s, ctl, fused_flag);
+void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag, const BatchState *bs) {
+    hipLaunchKernelGGL(k_seq_finish, dim3(1), dim3(64), 0, s, ctl, fused_flag, bs);
 }
 
 void launch_tile_scan(hipStream_t s, const TileSum *sums, uint32_t n_tiles, unsigned long long *offsets,

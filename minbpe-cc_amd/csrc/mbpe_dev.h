@@ -110,6 +110,11 @@ struct DevCtl {
     uint32_t sel_mode;          // 1: the next first gather lists block bounds (to find a threshold), not entries
     uint32_t n_ranks;           // shards of the stream (1 without multi-GPU); set at begin
     uint32_t size_hist[8];      // committed batch sizes: 1, 2-3, 4-7, ..., 128+ (statistics)
+    uint32_t n_skipped;         // dependent candidates passed over / batches cut short because one of them
+    uint32_t n_skip_cut;        //   had not fallen behind after all (statistics)
+    uint32_t skip_off;          // batches during which dependent candidates end the batch again (after a failed pass-over)
+    uint32_t skip_penalty;      // length of the next such period (doubles on failure, halves on success)
+    uint32_t skip_failed;       // set by k_validate for k_seq_finish
     unsigned long long n_sel_blocks;   // blocks read by the gathers (statistics)
 
 };
@@ -124,6 +129,7 @@ struct SelList {
     uint32_t eidx[kSelCap];
 };
 
+constexpr int kSkipMax = 32;
 struct BatchState {
     uint32_t key[kBatchMax];      // (first << 16) | second
     uint32_t eidx[kBatchMax];     // entry index in the pair table
@@ -131,6 +137,11 @@ struct BatchState {
     unsigned long long maxp[kBatchMax];     // largest packed (count, ~key) of the pairs merge j creates (k_delta_max)
     uint32_t adj_in[kBatchMax];   // sum_p ADJ[p][j]: matches of j directly after another match of the batch
     uint32_t adj_out[kBatchMax];  // sum_q ADJ[j][q]
+    // candidates passed over because they depend on an earlier member of the batch (see k_sel_pick)
+    uint32_t skip_n;
+    uint32_t skip_key[kSkipMax];
+    uint32_t skip_pos[kSkipMax];            // members accepted before it
+    unsigned long long skip_packed[kSkipMax];
 };
 
 // exchange buffer (u32 words): [single-merge header: m, adj, RankEdge x n_ranks]
@@ -223,7 +234,7 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const 
                            uint32_t *chg, uint32_t *list /* [n_tiles] scratch */, const BatchState *bs, DevCtl *ctl,
                            const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus);
 // fused_flag (optional): set to 1 when this sequence ran the fused pass
-void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag);
+void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag, const BatchState *bs);
 
 // compaction: exclusive scan of n_live over tiles, then scatter.  `offsets` needs
 // n_tiles + tile_scan_scratch(n_tiles) entries.

@@ -700,7 +700,7 @@ static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge excha
     launch_rewrite_marked(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->tile_list, c->bs, c->ctl, le, re,
                           endbit, c->n_cus);
     launch_patch_sums(c->stream, c->best, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 1);
-    launch_seq_finish(c->stream, c->ctl, c->seq_slot >= 0 ? c->seq_flags + c->seq_slot : nullptr);
+    launch_seq_finish(c->stream, c->ctl, c->seq_slot >= 0 ? c->seq_flags + c->seq_slot : nullptr, c->bs);
     if (multi)
         launch_rank_edge(c->stream, c->sums, c->n_tiles, reinterpret_cast<RankEdge *>(c->xb + 2) + c->rank, c->ctl,
                          c->xb);
@@ -1033,6 +1033,8 @@ int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
     c->stats.adapt_limit = c->begun ? c->h_ctl.adapt_limit : 0;
     c->stats.n_sel_blocks = c->begun ? c->h_ctl.n_sel_blocks : 0;
     for (int i = 0; i < 8; ++i) c->stats.size_hist[i] = c->begun ? c->h_ctl.size_hist[i] : 0;
+    c->stats.n_skipped = c->begun ? c->h_ctl.n_skipped : 0;
+    c->stats.n_skip_cut = c->begun ? c->h_ctl.n_skip_cut : 0;
     *out = c->stats;
     return MBPE_OK;
 }

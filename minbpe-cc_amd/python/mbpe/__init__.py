@@ -47,6 +47,7 @@ class Stats(ctypes.Structure):
         ("n_table_grows", ctypes.c_uint32), ("n_sel_fallback", ctypes.c_uint32),
         ("fused_launches", ctypes.c_uint32), ("ms_fused_kernel", ctypes.c_float), ("fused_slots", ctypes.c_uint64),
         ("n_sel_retry", ctypes.c_uint32), ("adapt_limit", ctypes.c_uint32), ("n_sel_blocks", ctypes.c_uint64), ("size_hist", ctypes.c_uint32 * 8),
+        ("n_skipped", ctypes.c_uint32), ("n_skip_cut", ctypes.c_uint32),
     ]
 
     def as_dict(self):

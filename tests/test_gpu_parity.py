@@ -381,7 +381,8 @@ def test_tie_heavy_text_large_vocab(tr, chunked):
     assert {k: v for k, v in tr.pairs_dict().items() if v} == {k: v for k, v in ost.table_dict().items() if v}
     ost.close()
     assert st["n_batches"] < len(m) // 4          # several merges per pass even here
-    assert st["n_sel_retry"] > 0                  # the overflow -> block bounds -> gather path was taken
+    if not chunked:
+        assert st["n_sel_retry"] > 0              # the overflow -> block bounds -> gather path was taken
 
 
 def test_one_giant_run(tr):
