@@ -566,9 +566,12 @@ __device__ __forceinline__ RunSeg run_seg_of(const TileSum &s, uint32_t t) {
 __device__ __forceinline__ unsigned long long run_pack(RunSeg r) { return (r.len << 1) | (r.full ? 1ull : 0ull); }
 __device__ __forceinline__ RunSeg run_unpack(unsigned long long v) { RunSeg r; r.len = v >> 1; r.full = v & 1ull; return r; }
 
-// the token of the (t,t) pair about to be merged, or 0xFFFFFFFF when this sequence merges something else
-__device__ __forceinline__ uint32_t run_token(const unsigned long long *best_ptr, const DevCtl *ctl, int seq) {
+// the token of the (t,t) pair about to be merged (alone, or as a member of a batch), or 0xFFFFFFFF when
+// this sequence merges no such pair
+__device__ __forceinline__ uint32_t run_token(const unsigned long long *best_ptr, const DevCtl *ctl, int seq,
+                                              const BatchState *bs) {
     if (seq) {
+        if (ctl->batch_n >= 2) return bs && bs->tt_index != kNoTT ? bs->tt_token : 0xFFFFFFFFu;
         if (ctl->batch_n != 1) return 0xFFFFFFFFu;
         best_ptr += ctl->k_done;
     }
@@ -595,10 +598,11 @@ __device__ __forceinline__ RunSeg run_chunk_join(const TileSum *sin, uint32_t n_
 
 __global__ __launch_bounds__(kRunThreads) void k_run_partial(const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                              const unsigned long long *best_ptr, const DevCtl *ctl,
-                                                             int seq, unsigned long long *__restrict__ part) {
+                                                             int seq, const BatchState *bs,
+                                                             unsigned long long *__restrict__ part) {
     __shared__ unsigned long long segs[kRunChunk];
     __shared__ unsigned long long sh[kRunThreads];
-    const uint32_t t = run_token(best_ptr, ctl, seq);
+    const uint32_t t = run_token(best_ptr, ctl, seq, bs);
     if (t == 0xFFFFFFFFu) return;
     run_chunk_join(sin, n_tiles, t, (uint64_t)blockIdx.x * kRunChunk, segs, sh);
     if (threadIdx.x == 0) {
@@ -610,12 +614,13 @@ __global__ __launch_bounds__(kRunThreads) void k_run_partial(const TileSum *__re
 
 __global__ __launch_bounds__(kRunThreads) void k_run_final(const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                            const unsigned long long *best_ptr, const DevCtl *ctl,
-                                                           int seq, const unsigned long long *__restrict__ part,
+                                                           int seq, const BatchState *bs,
+                                                           const unsigned long long *__restrict__ part,
                                                            const RankEdge *le, uint32_t *__restrict__ run_in) {
     __shared__ unsigned long long segs[kRunChunk];
     __shared__ unsigned long long sh[kRunThreads];
     __shared__ unsigned long long pre[kRunThreads];
-    const uint32_t t = run_token(best_ptr, ctl, seq);
+    const uint32_t t = run_token(best_ptr, ctl, seq, bs);
     if (t == 0xFFFFFFFFu) return;
     // everything before this chunk: each thread joins a slice of the chunk aggregates, thread 0 the slices
     const uint32_t nb = blockIdx.x, per = (nb + kRunThreads - 1) / kRunThreads;
@@ -1223,7 +1228,7 @@ __device__ __forceinline__ uint32_t pair_hash(uint32_t first, uint32_t second) {
     return (__umul24(second, 2531u) + first) & (kBuckets - 1u);      // one v_mad_u32_u24
 }
 
-__device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys) {
+__device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys, uint32_t fake) {
     for (uint32_t i = threadIdx.x; i < kBuckets; i += blockDim.x) {
         lut.bucket[i] = make_uint2(kEmptyPair, kEmptyPair);
         lut.bidx[i] = 0;
@@ -1232,7 +1237,9 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
     if (threadIdx.x == 0) {
         for (uint32_t j = 0; j < n_keys; ++j) {
             const uint32_t key = bs->key[j];
-            const uint32_t a = key >> 16, b = key & 0xFFFFu, h = pair_hash(a, b);
+            const uint32_t a = key >> 16;
+            const uint32_t b = (key & 0xFFFFu) == a ? fake : key & 0xFFFFu;     // (t,t): see tt_rename
+            const uint32_t h = pair_hash(a, b);
             const uint32_t kk = a | (b << 16);
             if (lut.bucket[h].x == kEmptyPair) { lut.bucket[h].x = kk; lut.bidx[h] = (uint16_t)j; }
             else { lut.bucket[h].y = kk; lut.bidx[h] = (uint16_t)(lut.bidx[h] | (j << 8)); }
@@ -1396,7 +1403,8 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
             bs->eidx[accepted] = cand_idx;
             bs->packed[accepted] = cand;
             bs->maxp[accepted] = 0;
-            bs->skip_n = 0;                 // (this kernel ends the batch at a dependent pair)
+            bs->skip_n = 0;                 // (this kernel ends the batch at a dependent pair
+            bs->tt_index = kNoTT;           //  and merges a (t,t) pair alone)
             best[k0 + accepted] = cand;
         }
         ++accepted;
@@ -1503,7 +1511,7 @@ constexpr int kPickThreads = 1024;
 __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchState *bs, const SelList *sel,
                                                            unsigned long long *best, uint32_t n_target,
                                                            uint32_t max_batch, uint32_t fused_min,
-                                                           uint32_t n_ranks, int attempt) {
+                                                           uint32_t n_ranks, int attempt, uint32_t fake_id) {
     __shared__ unsigned long long sp[kSelCap];
     __shared__ uint32_t si[kSelCap];
     const uint32_t tid = threadIdx.x;
@@ -1597,11 +1605,15 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         //  earlier pair's -- and a failed pass-over costs a stream pass; after a failure dependent
         //  pairs end the batch again for a while, see k_seq_finish)
         const bool skip_allowed = ctl->skip_off == 0;
+        bool have_tt = false;
+        if (tid == 0) bs->tt_index = kNoTT;
         for (; accepted < limit && ci < n_l; ++ci) {
             const unsigned long long cand = sp[ci];
             const uint32_t count = (uint32_t)(cand >> 32), key = ~(uint32_t)cand;
-            const uint32_t a = key >> 16, b = key & 0xFFFFu, h = pair_hash(a, b);
-            const bool single = count == 0 || a == b;
+            const uint32_t a = key >> 16, b = key & 0xFFFFu;
+            const bool tt = a == b && count != 0;      // (t,t): a member like any other once renamed (tt_rename),
+            const bool single = count == 0 || (tt && have_tt);        // but only one per batch
+            const uint32_t h = pair_hash(a, tt ? fake_id : b);
             if (accepted > 0) {
                 bool c1 = false;
                 uint32_t same_l = 0;
@@ -1612,7 +1624,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 }
                 const unsigned long long conf = __ballot(c1);
                 const uint32_t same = wave_sum(same_l);
-                if (single) { cut = 3u; break; }
+                if (single || (tt && conf != 0ull)) { cut = 3u; break; }
                 if (conf != 0ull && n_skip < (uint32_t)kSkipMax && skip_allowed) {
                     // Depends on an earlier member (shares a token with it the wrong way round): the
                     // earlier merge eats some of its occurrences, so its count will have dropped by the
@@ -1638,7 +1650,9 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 bs->packed[accepted] = cand;
                 bs->maxp[accepted] = 0;
                 best[k0 + accepted] = cand;
+                if (tt) { bs->tt_index = accepted; bs->tt_token = a; }
             }
+            have_tt |= tt;
             ++accepted;
             if (single) { cut = 3u; ++ci; break; }
         }
@@ -1674,6 +1688,66 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
     }
 }
 
+
+// A (t,t) member of a batch.  Its matches are every second token of a run of t, counted from the
+// run's start, that has a successor in the run.  Renaming, in registers only, the tokens at the odd
+// positions of every run to an id that no token has (idmask - 1) turns the pair into an ordinary
+// one, (t, fake): no two of its occurrences overlap, every renamed token is the second token of a
+// match and disappears, and all the batch machinery applies unchanged.  The position of a token in
+// its run needs the length of the run before the lane (a segmented scan over the lanes) and before the
+// tile (run_in, from k_run_final); the neighbour tokens taken from the summaries are renamed alike.
+// A t that ends its chunk can be the second token of a match but ends the run.
+template <bool CHUNKED>
+__device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, uint32_t t, uint32_t rb_small) {
+    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    constexpr uint32_t fake = idmask - 1u;
+    const uint32_t lane = lane_id();
+    bool has = false, all_t = true;
+    uint32_t trail = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (s[j] != kHole) {
+            has |= (s[j] & idmask) == t;
+            if (s[j] == t) ++trail; else { trail = 0; all_t = false; }
+        }
+    }
+    uint32_t r = 0;                    // raw t's at the end of the tile (parity)
+    if (__ballot(has) != 0ull) {
+        // inclusive scan of (all_t, trail): R after L -> R.all ? (L.all, L.trail + R.trail) : R
+        uint32_t sa = all_t ? 1u : 0u, st = trail;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t oa = __shfl_up(sa, d, kWave), ot = __shfl_up(st, d, kWave);
+            if (lane >= (uint32_t)d && sa) { st += ot; sa = oa; }
+        }
+        uint32_t ea = __shfl_up(sa, 1, kWave), et = __shfl_up(st, 1, kWave);
+        if (lane == 0) { ea = 1; et = 0; }
+        uint32_t run = ea ? et + rb_small : et;          // only its parity is used
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (s[j] != kHole) {
+                const bool raw_t = s[j] == t;
+                if ((s[j] & idmask) == t && (run & 1u)) s[j] = fake | (s[j] & endbit);
+                run = raw_t ? run + 1u : 0u;
+            }
+        }
+        r = rlane(run, kWave - 1);
+    }
+    // the two tokens after the tile continue the count ...
+    if (h.n1 != kHole) {
+        const bool raw_t = h.n1 == t;
+        if ((h.n1 & idmask) == t && (r & 1u)) h.n1 = fake | (h.n1 & endbit);
+        r = raw_t ? r + 1u : 0u;
+        if (h.n2 != kHole && (h.n2 & idmask) == t && (r & 1u)) h.n2 = fake | (h.n2 & endbit);
+    }
+    // ... and the two before it end a run of rb tokens: p1 is number rb - 1, p2 number rb - 2
+    if (h.p1 == t) {
+        const bool p2_t = h.p2 == t;
+        if (!(rb_small & 1u)) h.p1 = fake;
+        if (p2_t && (rb_small & 1u)) h.p2 = fake;
+    }
+}
 
 // exact neighbours of every slot, two deep on both sides (shared by the scan
 // and rewrite passes of a batch)
@@ -1736,7 +1810,8 @@ __device__ __forceinline__ Neigh tile_neighbours(const uint32_t s[8], const Halo
 template <bool CHUNKED, int DIAG = 0>
 __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, const uint32_t s[8], const Halo h,
                                                const BatchLut &lut, uint32_t n_keys, uint32_t *hdr_adj,
-                                               uint32_t *LR, DeltaCache &dc, bool dc_on) {
+                                               uint32_t *LR, DeltaCache &dc, bool dc_on, uint32_t tt_idx,
+                                               uint32_t &lane_tt) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     const Neigh nb = tile_neighbours(s, h);
@@ -1769,6 +1844,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
             is_a = true;
             any = true;
             const int ja = lut_index(lut, self, n1 & idmask);
+            lane_tt += (uint32_t)ja == tt_idx ? 1u : 0u;     // matches of the (t,t) member (kNoTT: none)
             if (p1 != kHole && !(p1 & endbit)) {
                 if (p2 != kHole && pair_test(lut, p2, p1)) {               // two matches touch
                     const int jp = lut_index(lut, p2, p1);
@@ -1785,13 +1861,14 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
     if (__ballot(any) != 0ull && lane_id() == 0) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
 }
 
-template <bool CHUNKED, bool HOT, int DIAG = 0>
+template <bool CHUNKED, bool HOT, bool TT, int DIAG = 0>
 __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *tok0, const uint16_t *tok1,
                                                               const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                               uint32_t *__restrict__ chg, const BatchState *bs,
                                                               uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
                                                               const DevCtl *ctl, const RankEdge *le,
-                                                              const RankEdge *re) {
+                                                              const RankEdge *re,
+                                                              const uint32_t *__restrict__ run_in) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     __shared__ BatchLut lut;
     const uint32_t lane = lane_id();
@@ -1800,11 +1877,14 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
     __shared__ DeltaCache dc;
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2 || ctl->fused) return;
+    if ((bs->tt_index != kNoTT) != TT) return;      // (see k_fused_batch)
+    const uint32_t tt_idx = TT ? bs->tt_index : kNoTT, tt_tok = TT ? bs->tt_token : kHole;
+    uint32_t lane_tt = 0;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
-    lut_build(lut, bs, n_keys);
+    lut_build(lut, bs, n_keys, idmask - 1u);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     if (tile < n_tiles) {
 
@@ -1836,6 +1916,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
             } else {
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
+            if (TT) tt_rename<CHUNKED>(s, h, tt_tok, run_in[tile]);
             // first live token of the lanes after this one (exact), then the candidate
             // test: some slot and its next live token form one of the batch pairs
             uint32_t lf = kHole;
@@ -1857,7 +1938,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             bool work = __ballot(cand) != 0ull || pair_test(lut, h.p1, tile_first & idmask);
             if (DIAG == 2) { asm volatile("" :: "v"((uint32_t)cand)); work = false; }
-            if (work) scan_tile_full<CHUNKED, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, dc, dc_on);
+            if (work) scan_tile_full<CHUNKED, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, dc, dc_on, tt_idx, lane_tt);
         }
         if (!v1) break;
         tile += n_waves;
@@ -1866,6 +1947,10 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
     }
     }
     if (dc_on) dc_flush(dc, LR);
+    if (TT) {
+        const uint32_t m = wave_sum(lane_tt);
+        if (lane == 0 && m) atomicAdd(&hdr_m[tt_idx], m);
+    }
 }
 
 // ---- the fused pass of a large batch ----------------------------------------------------
@@ -1887,8 +1972,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
 // match is.
 
 template <bool CHUNKED, int DIAG = 0>
-__device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint32_t cj[8], uint32_t Am,
-                                                 unsigned long long m_live, uint32_t c_init, const Halo h,
+__device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, uint32_t tt_tok, uint32_t tt_idx,
+                                                 uint32_t &lane_tt, const uint32_t s[8], const uint32_t cj[8],
+                                                 uint32_t Am, unsigned long long m_live, uint32_t c_init, const Halo h,
                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
@@ -1919,7 +2005,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
     const uint32_t touch = Am & ((((Bm << 1) | bin) + Hm) & Lm);     // starts a match right after another one
 
     const unsigned long long ab = __ballot((Am | Bm) != 0u);
-    if (ab == 0ull) return pack8(s);
+    if (ab == 0ull) return q_orig;
 
     // last live token of every lane and, where it starts a match, the index of that match
     uint32_t ll = kHole;
@@ -1948,7 +2034,10 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
         if ((ABm >> j) & 1u) {               // one guarded region per position serves both roles
             const bool is_a = (Am >> j) & 1u;
             uint32_t ja = pj;
-            if (is_a) ja = (uint32_t)lut_index(lut, self, cj[j] & idmask);
+            if (is_a) {
+                ja = (uint32_t)lut_index(lut, self, cj[j] & idmask);
+                lane_tt += ja == tt_idx ? 1u : 0u;          // matches of the (t,t) member (kNoTT: none)
+            }
             // first token of a match: (p1, a) -> (p1, X); second token: (b, n1) -> (X, n1)
             const uint32_t nb = is_a ? p1 : cj[j];                       // the neighbour the match loses
             const bool counted = is_a ? (p1 != kHole && !(p1 & endbit)) : (!(self & endbit) && cj[j] != kHole);
@@ -1968,6 +2057,11 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
         out[j] = nv;
     }
 
+    if (tt_tok != kHole) {              // (every renamed token was the second token of a match; be safe)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (out[j] != kHole && (out[j] & idmask) == idmask - 1u) out[j] = tt_tok | (out[j] & endbit);
+    }
     const uint32_t removed = rfl(wave_sum(__popc(Bm)));
     wave_rm += removed;
     // New summary.  Heads and tails only change when a match touches one of the first two or
@@ -1995,13 +2089,14 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint32_t s[8], const uint
 
 // (7 waves per SIMD: the cold instantiation meets it with two spilled registers, which is cheaper than
 //  running with 6 waves; 8 would spill ten and is slower.  The delta cache of the HOT one allows 5.)
-template <bool CHUNKED, bool HOT, int DIAG = 0>
+template <bool CHUNKED, bool HOT, bool TT, int DIAG = 0>
 __global__ __launch_bounds__(kMergeThreads, HOT ? 5 : 7) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
                                                                const TileSum *__restrict__ sin,
                                                                TileSum *__restrict__ sout, uint32_t n_tiles,
                                                                uint32_t *__restrict__ chg, const BatchState *bs,
                                                                uint32_t *hdr_adj, uint32_t *LR, DevCtl *ctl,
-                                                               const RankEdge *le, const RankEdge *re) {
+                                                               const RankEdge *le, const RankEdge *re,
+                                                               uint32_t *hdr_m, const uint32_t *__restrict__ run_in) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     __shared__ BatchLut lut;
     const uint32_t lane = lane_id();
@@ -2010,13 +2105,17 @@ __global__ __launch_bounds__(kMergeThreads, HOT ? 5 : 7) void k_fused_batch(uint
     __shared__ DeltaCache dc;
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2 || !ctl->fused) return;
+    // (the instantiation with the (t,t) code only runs for batches that have such a member, like HOT)
+    if ((bs->tt_index != kNoTT) != TT) return;
+    const uint32_t tt_idx = TT ? bs->tt_index : kNoTT, tt_tok = TT ? bs->tt_token : kHole;
+    uint32_t lane_tt = 0;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     uint16_t *dst = ctl->cur ? tok0 : tok1;
     const uint32_t X0 = 256u + ctl->k_done;
     if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
-    lut_build(lut, bs, n_keys);
+    lut_build(lut, bs, n_keys, idmask - 1u);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     uint32_t wave_rm = 0;        // uniform
     if (tile < n_tiles) {
@@ -2048,6 +2147,7 @@ __global__ __launch_bounds__(kMergeThreads, HOT ? 5 : 7) void k_fused_batch(uint
             } else {
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
+            if (TT) tt_rename<CHUNKED>(s, h, tt_tok, run_in[tile]);
             uint32_t lf = kHole;
 #pragma unroll
             for (int j = 7; j >= 0; --j) lf = s[j] != kHole ? s[j] : lf;
@@ -2069,8 +2169,9 @@ __global__ __launch_bounds__(kMergeThreads, HOT ? 5 : 7) void k_fused_batch(uint
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
                 const uint32_t Am = nohit ^ 0xFFu;
-                outq = fused_tile_full<CHUNKED, DIAG>(s, cj, Am, m_live, c_init, h, tile_first, old_x, old_y, old_z, lut,
-                                                X0, tile, sout, chg, hdr_adj, LR, dc, dc_on, wave_rm);
+                outq = fused_tile_full<CHUNKED, DIAG>(t0.q, tt_tok, tt_idx, lane_tt, s, cj, Am, m_live, c_init, h, tile_first,
+                                                old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
+                                                wave_rm);
             }
         }
         reinterpret_cast<uint4 *>(dst)[(uint64_t)tile * kWave + lane] = outq;
@@ -2083,6 +2184,10 @@ __global__ __launch_bounds__(kMergeThreads, HOT ? 5 : 7) void k_fused_batch(uint
     }
     if (dc_on) dc_flush(dc, LR);
     if (lane == 0 && wave_rm) atomicAdd(&ctl->rm, wave_rm);
+    if (TT) {                           // matches of the (t,t) member: its count is not simply the pair's count
+        const uint32_t m = wave_sum(lane_tt);
+        if (lane == 0 && m) atomicAdd(&hdr_m[tt_idx], m);
+    }
 }
 
 // Validation (after the all-reduce in a multi-GPU run).  Merge j creates the pairs (x, X_j) with
@@ -2252,10 +2357,12 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
             }
         }
     }
-    if (gid < commit) {
-        // every occurrence of an (a,b), a != b, pair is merged: its count drops to 0
-        const uint32_t m = (uint32_t)(bs->packed[gid] >> 32);
-        if (m) table_add(t, ctl, bs->key[gid], -(int32_t)m, false);
+    if (gid < commit || gid == bs->tt_index) {
+        // every occurrence of an (a,b), a != b, pair is merged: its count drops to 0; a (t,t) member
+        // loses its matches, counted by the stream pass (overlapping occurrences: m < count)
+        uint32_t m = (uint32_t)(bs->packed[gid] >> 32);
+        if (gid == bs->tt_index) { m = hdr_m[gid]; hdr_m[gid] = 0; }
+        if (m && gid < commit) table_add(t, ctl, bs->key[gid], -(int32_t)m, false);
     }
 }
 
@@ -2291,7 +2398,7 @@ __device__ __forceinline__ void dense_insert_run(const PairTable &t, bool active
 }
 
 __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *ctl, const BatchState *bs,
-                                                           uint32_t *hdr_adj, uint32_t *LR) {
+                                                           uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR) {
     __shared__ uint2 tile[kApplyTile][kApplyTile + 1];
     const uint32_t n = ctl->batch_n;
     if (n < 2) return;
@@ -2375,10 +2482,12 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
             }
         }
     }
-    if (gid < commit) {
-        // every occurrence of an (a,b), a != b, pair is merged: its count drops to 0
-        const uint32_t m = (uint32_t)(bs->packed[gid] >> 32);
-        if (m) table_add(t, ctl, bs->key[gid], -(int32_t)m, false);
+    if (gid < commit || gid == bs->tt_index) {
+        // every occurrence of an (a,b), a != b, pair is merged: its count drops to 0; a (t,t) member
+        // loses its matches, counted by the stream pass (overlapping occurrences: m < count)
+        uint32_t m = (uint32_t)(bs->packed[gid] >> 32);
+        if (gid == bs->tt_index) { m = hdr_m[gid]; hdr_m[gid] = 0; }
+        if (m && gid < commit) table_add(t, ctl, bs->key[gid], -(int32_t)m, false);
     }
 }
 
@@ -2402,23 +2511,26 @@ __global__ void k_list_marked(const uint32_t *__restrict__ chg, uint32_t n_words
     }
 }
 
-template <bool CHUNKED>
+template <bool CHUNKED, bool TT>
 __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *tok0, uint16_t *tok1,
                                                                   const TileSum *__restrict__ sin,
                                                                   TileSum *__restrict__ sout, uint32_t n_tiles,
                                                                   uint32_t *__restrict__ chg,
                                                                   const uint32_t *__restrict__ list,
                                                                   const BatchState *bs, DevCtl *ctl,
-                                                                  const RankEdge *le, const RankEdge *re) {
+                                                                  const RankEdge *le, const RankEdge *re,
+                                                                  const uint32_t *__restrict__ run_in) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     __shared__ BatchLut lut;
     if (ctl->batch_n < 2 || (ctl->fused && ctl->commit_n == ctl->batch_n)) return;
     uint16_t *tok = ctl->cur ? tok1 : tok0;
     const uint32_t n_keys = ctl->commit_n;
+    if ((bs->tt_index < n_keys) != TT) return;      // (t,t) member inside the kept prefix: see k_fused_batch
+    const uint32_t tt_tok = TT ? bs->tt_token : kHole;
     const uint32_t X0 = 256u + ctl->k_done;
     const uint32_t n_list = ctl->n_marked;
-    lut_build(lut, bs, n_keys);
+    lut_build(lut, bs, n_keys, idmask - 1u);
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
@@ -2450,6 +2562,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *tok0
         } else {
             h = halo_slow(sin, n_tiles, tile, le, re);
         }
+        if (TT) tt_rename<CHUNKED>(s, h, tt_tok, run_in[tile]);
         const Neigh nb = tile_neighbours(s, h);
         bool changed = false, a1 = false, first = true;
         uint32_t p1 = nb.p1_in, my_rm = 0;
@@ -2471,6 +2584,11 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *tok0
             }
             a1 = is_a;
             p1 = self;
+        }
+        if (TT) {                           // (every renamed token was the second token of a match; be safe)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s[j] != kHole && (s[j] & idmask) == idmask - 1u) s[j] = tt_tok | (s[j] & endbit);
         }
         if (changed) reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
         wave_rm += my_rm;
@@ -2819,13 +2937,14 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileSum *sin, TileSum *sout, uint32_t n_tiles,
                   uint32_t *chg, const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *LR,
                   DevCtl *ctl, uint32_t *m_adj, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus,
-                  int seq, unsigned long long *run_part, uint32_t *run_in) {
+                  int seq, unsigned long long *run_part, uint32_t *run_in, const BatchState *bs) {
     if (!n_tiles) return;
     {   // runs of t before every tile, for a (t,t) pair (the kernels return at once for any other pair)
         const uint32_t n_chunks = (n_tiles + kRunChunk - 1) / kRunChunk;
-        hipLaunchKernelGGL(k_run_partial, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, run_part);
-        hipLaunchKernelGGL(k_run_final, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, run_part,
-                           left_edge, run_in);
+        hipLaunchKernelGGL(k_run_partial, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, bs,
+                           run_part);
+        hipLaunchKernelGGL(k_run_final, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, bs,
+                           run_part, left_edge, run_in);
     }
     static const int occ_c = resident_blocks(k_merge<true, false, 0>), occ_b = resident_blocks(k_merge<false, false, 0>);
     const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
@@ -2879,13 +2998,14 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus, int n_ranks) {
+                         int n_cus, int n_ranks, uint32_t endbit) {
+    const uint32_t fake_id = (endbit ? 0x7FFFu : 0xFFFFu) - 1u;      // see tt_rename
     if (sel) {
         const int blocks = (n_cus > 0 ? n_cus : 256) * 4;
         for (int attempt = 0; attempt < 3; ++attempt) {
             hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target, attempt);
             hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
-                               fused_min, (uint32_t)n_ranks, attempt);
+                               fused_min, (uint32_t)n_ranks, attempt, fake_id);
         }
     }
     hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch,
@@ -2895,72 +3015,88 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
                         uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                        int n_cus) {
+                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in) {
     if (!n_tiles) return;
-    static const int occ_c = resident_blocks(k_fused_batch<true, false, 0>), occ_b = resident_blocks(k_fused_batch<false, false, 0>);
+    static const int occ_c = resident_blocks(k_fused_batch<true, false, false, 0>), occ_b = resident_blocks(k_fused_batch<false, false, false, 0>);
     const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
 #ifdef MBPE_DIAG
     const int diag = getenv("MBPE_FUSED_DIAG") ? atoi(getenv("MBPE_FUSED_DIAG")) : 0;   // (re-read: set after warm-up)
     if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_fused_batch<false, false, 2>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs,
-                           hdr_adj, LR, ctl, left_edge, right_edge);
+        hipLaunchKernelGGL((k_fused_batch<false, false, false, 2>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs,
+                           hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in);
         return;
     }
 #endif
     if (endbit) {
-        hipLaunchKernelGGL((k_fused_batch<true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge);
-        hipLaunchKernelGGL((k_fused_batch<true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge);
+        hipLaunchKernelGGL((k_fused_batch<true, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        hipLaunchKernelGGL((k_fused_batch<true, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        hipLaunchKernelGGL((k_fused_batch<true, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        hipLaunchKernelGGL((k_fused_batch<true, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
     } else {
-        hipLaunchKernelGGL((k_fused_batch<false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge);
-        hipLaunchKernelGGL((k_fused_batch<false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge);
+        hipLaunchKernelGGL((k_fused_batch<false, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        hipLaunchKernelGGL((k_fused_batch<false, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        hipLaunchKernelGGL((k_fused_batch<false, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        hipLaunchKernelGGL((k_fused_batch<false, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
     }
 }
 
 void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1, const TileSum *sums, uint32_t n_tiles,
                        uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
                        const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                       int n_cus) {
+                       int n_cus, const uint32_t *run_in) {
     if (!n_tiles) return;
-    static const int occ_c = resident_blocks(k_scan_batch<true, false, 0>),
-                     occ_b = resident_blocks(k_scan_batch<false, false, 0>);
+    static const int occ_c = resident_blocks(k_scan_batch<true, false, false, 0>),
+                     occ_b = resident_blocks(k_scan_batch<false, false, false, 0>);
     const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_SCAN_DIAG") ? atoi(getenv("MBPE_SCAN_DIAG")) : 0;
     if (diag == 1 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, false, 1>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
-                           ctl, left_edge, right_edge);
+        hipLaunchKernelGGL((k_scan_batch<false, false, false, 1>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+                           ctl, left_edge, right_edge, run_in);
         return;
     }
     if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, false, 2>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
-                           ctl, left_edge, right_edge);
+        hipLaunchKernelGGL((k_scan_batch<false, false, false, 2>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+                           ctl, left_edge, right_edge, run_in);
         return;
     }
     if (diag == 3 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, false, 3>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
-                           ctl, left_edge, right_edge);
+        hipLaunchKernelGGL((k_scan_batch<false, false, false, 3>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+                           ctl, left_edge, right_edge, run_in);
         return;
     }
     if (diag == 4 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, false, 4>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
-                           ctl, left_edge, right_edge);
+        hipLaunchKernelGGL((k_scan_batch<false, false, false, 4>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
+                           ctl, left_edge, right_edge, run_in);
         return;
     }
 #endif
     if (endbit) {
-        hipLaunchKernelGGL((k_scan_batch<true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge);
-        hipLaunchKernelGGL((k_scan_batch<true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge);
+        hipLaunchKernelGGL((k_scan_batch<true, false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge, run_in);
+        hipLaunchKernelGGL((k_scan_batch<true, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge, run_in);
+        hipLaunchKernelGGL((k_scan_batch<true, true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge, run_in);
+        hipLaunchKernelGGL((k_scan_batch<true, true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge, run_in);
     } else {
-        hipLaunchKernelGGL((k_scan_batch<false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge);
-        hipLaunchKernelGGL((k_scan_batch<false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge);
+        hipLaunchKernelGGL((k_scan_batch<false, false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge, run_in);
+        hipLaunchKernelGGL((k_scan_batch<false, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge, run_in);
+        hipLaunchKernelGGL((k_scan_batch<false, true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge, run_in);
+        hipLaunchKernelGGL((k_scan_batch<false, true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
+                           left_edge, right_edge, run_in);
     }
 }
 
@@ -2978,7 +3114,7 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
         uint32_t grid = ((id_upper + kApplyTile - 1) / kApplyTile) * (kBatchMax / kApplyTile);
         const uint32_t need = (kBatchMax * kBatchMax + 255) / 256;          // the ADJ cells, one thread each
         if (grid < need) grid = need;
-        hipLaunchKernelGGL(k_apply_batch_dense, dim3(grid), dim3(256), 0, s, t, ctl, bs, hdr_adj, LR);
+        hipLaunchKernelGGL(k_apply_batch_dense, dim3(grid), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     } else {
         hipLaunchKernelGGL(k_apply_batch, dim3(blocks), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     }
@@ -2986,17 +3122,23 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 
 void launch_rewrite_marked(hipStream_t s, uint16_t *tok, uint16_t *tok1, const TileSum *sums, TileSum *side, uint32_t n_tiles,
                            uint32_t *chg, uint32_t *list, const BatchState *bs, DevCtl *ctl,
-                           const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus) {
+                           const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus,
+                           const uint32_t *run_in) {
     if (!n_tiles) return;
     const uint32_t n_words = (n_tiles + 31u) / 32u;
     hipLaunchKernelGGL(k_list_marked, dim3((n_words + 255) / 256), dim3(256), 0, s, chg, n_words, list, ctl);
     const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
-    if (endbit)
-        hipLaunchKernelGGL(k_rewrite_marked<true>, grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
-                           left_edge, right_edge);
-    else
-        hipLaunchKernelGGL(k_rewrite_marked<false>, grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
-                           left_edge, right_edge);
+    if (endbit) {
+        hipLaunchKernelGGL((k_rewrite_marked<true, false>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
+                           left_edge, right_edge, run_in);
+        hipLaunchKernelGGL((k_rewrite_marked<true, true>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
+                           left_edge, right_edge, run_in);
+    } else {
+        hipLaunchKernelGGL((k_rewrite_marked<false, false>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
+                           left_edge, right_edge, run_in);
+        hipLaunchKernelGGL((k_rewrite_marked<false, true>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
+                           left_edge, right_edge, run_in);
+    }
 }
 
 void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag, const BatchState *bs) {

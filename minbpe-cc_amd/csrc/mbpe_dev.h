@@ -130,6 +130,7 @@ struct SelList {
 };
 
 constexpr int kSkipMax = 32;
+constexpr uint32_t kNoTT = 0xFFFFFFFFu;
 struct BatchState {
     uint32_t key[kBatchMax];      // (first << 16) | second
     uint32_t eidx[kBatchMax];     // entry index in the pair table
@@ -137,6 +138,10 @@ struct BatchState {
     unsigned long long maxp[kBatchMax];     // largest packed (count, ~key) of the pairs merge j creates (k_delta_max)
     uint32_t adj_in[kBatchMax];   // sum_p ADJ[p][j]: matches of j directly after another match of the batch
     uint32_t adj_out[kBatchMax];  // sum_q ADJ[j][q]
+    // a (t,t) member (at most one per batch): its index, or kNoTT; its matches are every second token of a
+    // run of t, see tt_rename in kernels.hip
+    uint32_t tt_index;
+    uint32_t tt_token;
     // candidates passed over because they depend on an earlier member of the batch (see k_sel_pick)
     uint32_t skip_n;
     uint32_t skip_key[kSkipMax];
@@ -195,7 +200,8 @@ void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileS
                   uint32_t endbit, uint32_t *LR, DevCtl *ctl, uint32_t *m_adj /* [m, adj] accumulators */,
                   const RankEdge *left_edge, const RankEdge *right_edge, int n_cus, int seq,
                   unsigned long long *run_part /* tile_scan_scratch(n_tiles) entries */,
-                  uint32_t *run_in /* n_tiles entries: run of t before every tile, for (t,t) pairs */);
+                  uint32_t *run_in /* n_tiles entries: run of t before every tile, for (t,t) pairs */,
+                  const BatchState *bs /* seq != 0: a batch may hold a (t,t) member */);
 // seq != 0: the kernel runs inside a batch sequence: it reads the merge index
 // from ctl->k_done and returns at once unless the selected batch has one pair;
 // tok / tok_other are then token buffers 0 / 1 and ctl->cur picks the live one
@@ -214,25 +220,26 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 // prefix), then k_select_batch (walks the argmax bounds one pair at a time) if that could not be used
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus, int n_ranks);
+                         int n_cus, int n_ranks, uint32_t endbit);
 // (three gather + pick attempts are enqueued: when the first gather overflows its list -- many equal
 //  counts -- the second lists the block bounds to find a threshold and the third gathers with it)
 // small batch: count the deltas and mark the tiles (the rewrite follows validation)
 void launch_scan_batch(hipStream_t s, const uint16_t *tok0, const uint16_t *tok1, const TileSum *sums,
                        uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                        uint32_t *LR, const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge,
-                       uint32_t endbit, int n_cus);
+                       uint32_t endbit, int n_cus, const uint32_t *run_in);
 // large batch (ctl->fused): count the deltas and write the merged stream to the other buffer
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
                         uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                        int n_cus);
+                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in);
 // k_delta_max + k_validate + k_apply_batch
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                          uint32_t *LR, uint32_t id_upper);
 void launch_rewrite_marked(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side, uint32_t n_tiles,
                            uint32_t *chg, uint32_t *list /* [n_tiles] scratch */, const BatchState *bs, DevCtl *ctl,
-                           const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus);
+                           const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus,
+                           const uint32_t *run_in /* as for launch_merge: used when the batch has a (t,t) member */);
 // fused_flag (optional): set to 1 when this sequence ran the fused pass
 void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag, const BatchState *bs);
 

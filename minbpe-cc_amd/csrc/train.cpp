@@ -137,6 +137,7 @@ struct mbpe_ctx {
     uint32_t *chg = nullptr;     // bitmap of those tiles
     uint32_t *tile_list = nullptr;   // the same as a dense list (batch rewrite pass)
     SelList *sel = nullptr;          // candidates of the threshold selection
+    uint32_t *run_in = nullptr;      // per tile: run of t before it, for (t,t) pairs (k_run_final)
     int seq_slot = -1;               // index of the sequence being enqueued within its group (opt_time_kernels)
     unsigned long long *offsets = nullptr;
 
@@ -219,7 +220,7 @@ void free_training(mbpe_ctx *c) {
     dfree(c->tab.hslot); dfree(c->tab.ekey); dfree(c->tab.ecnt); dfree(c->tab.cells);
     dfree(c->tab.bmax); dfree(c->tab.smax);
     dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->xb); dfree(c->xb0);
-    dfree(c->d_left); dfree(c->d_right); dfree(c->bs); dfree(c->sel); dfree(c->seq_flags);
+    dfree(c->d_left); dfree(c->d_right); dfree(c->bs); dfree(c->sel); dfree(c->seq_flags); dfree(c->run_in);
     c->LR = nullptr;
     c->pending = 0;
     c->begun = false;
@@ -568,6 +569,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     c->LR = c->xb + c->hdr_words + c->hdrb_words;
     HIPCHK(hipMalloc(&c->bs, sizeof(BatchState)));
     HIPCHK(hipMalloc(&c->sel, sizeof(SelList)));
+    HIPCHK(hipMalloc(&c->run_in, ((size_t)c->n_tiles + 64) * 4));
     HIPCHK(hipMalloc(&c->seq_flags, 4096 * 4));
     HIPCHK(hipMemsetAsync(c->bs, 0, sizeof(BatchState), c->stream));
     c->k_upper = 0;
@@ -635,7 +637,7 @@ static void step_local(mbpe_ctx *c, int ev_slot) {
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     launch_merge(c->stream, c->tok[c->cur], c->tok[1 - c->cur], c->sums, c->side, c->n_tiles, c->chg, c->best + c->k, X, endbit, c->LR,
                  c->ctl, &c->ctl->m, multi ? c->d_left : nullptr, multi ? c->d_right : nullptr, c->n_cus, 0,
-                 c->offsets + c->n_tiles, c->tile_list);
+                 c->offsets + c->n_tiles, c->run_in, nullptr);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
     if (multi) {
         launch_patch_sums(c->stream, c->best + c->k, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 0);
@@ -672,16 +674,16 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
     launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best,
                         c->n_target, (uint32_t)c->opt_max_batch, (uint32_t)c->opt_fused_min, c->n_cus,
-                        std::max(1, c->n_ranks));
+                        std::max(1, c->n_ranks), endbit);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     // (the live token buffer is ctl->cur: a fused pass flips it without the host knowing)
     launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
-                 multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1, c->offsets + c->n_tiles, c->tile_list);
+                 multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1, c->offsets + c->n_tiles, c->run_in, c->bs);
     launch_scan_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
-                      c->ctl, le, re, endbit, c->n_cus);
+                      c->ctl, le, re, endbit, c->n_cus, c->run_in);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev_f[2 * ev_slot], c->stream);
     launch_fused_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->bs, c->hdr_adj, c->LR,
-                       c->ctl, le, re, endbit, c->n_cus);
+                       c->ctl, le, re, endbit, c->n_cus, c->hdr_m, c->run_in);
     if (ev_slot >= 0) {
         (void)hipEventRecord(c->kev_f[2 * ev_slot + 1], c->stream);
         (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
@@ -698,7 +700,7 @@ static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge excha
     launch_apply(c->stream, c->tab, c->ctl, c->best, id_upper, c->LR, multi ? c->xb : nullptr, c->sums, c->side,
                  c->chg, c->n_tiles, 1);
     launch_rewrite_marked(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->tile_list, c->bs, c->ctl, le, re,
-                          endbit, c->n_cus);
+                          endbit, c->n_cus, c->run_in);
     launch_patch_sums(c->stream, c->best, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 1);
     launch_seq_finish(c->stream, c->ctl, c->seq_slot >= 0 ? c->seq_flags + c->seq_slot : nullptr, c->bs);
     if (multi)
