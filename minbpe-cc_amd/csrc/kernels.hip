@@ -508,15 +508,28 @@ struct Halo { uint32_t p2, p1, n1, n2; };
 // Neighbour tokens of a tile when the adjacent summaries cannot answer
 // directly (first / last tile, or a neighbour with fewer than two live
 // tokens): walk the summaries, then the rank edges of a multi-GPU run.
-__device__ Halo halo_slow(const TileSum *sin, uint32_t n_tiles, uint32_t tile, const RankEdge *le,
-                          const RankEdge *re) {
+// Every read is a whole-dword load from a uniform address through a constant-
+// address-space pointer (nothing writes the summaries or the edges while a pass
+// runs), which the compiler turns into scalar loads: a vector load here would make
+// the callers wait for vmcnt(0), i.e. for the tiles they have prefetched.
+#define MBPE_CONST_AS __attribute__((address_space(4)))
+__device__ __forceinline__ Halo halo_slow(const TileSum *__restrict__ sin, uint32_t n_tiles, uint32_t tile,
+                                          const RankEdge *__restrict__ le, const RankEdge *__restrict__ re) {
     Halo h;
     h.p1 = h.p2 = h.n1 = h.n2 = kHole;
+    typedef unsigned int su4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int su2 __attribute__((ext_vector_type(2)));
+    const MBPE_CONST_AS su4 *sq = (const MBPE_CONST_AS su4 *)(uintptr_t)sin;
+    const MBPE_CONST_AS su2 *lq = (const MBPE_CONST_AS su2 *)(uintptr_t)le;
+    const MBPE_CONST_AS su2 *rq = (const MBPE_CONST_AS su2 *)(uintptr_t)re;
     int need = 2;
     for (int64_t j = (int64_t)tile - 1; need && j >= -1; --j) {
         uint32_t nl, t0, t1;
-        if (j >= 0) { TileSum s = sin[j]; nl = s.n_live; t0 = s.tail0; t1 = s.tail1; }
-        else if (le) { t0 = le->tail0; t1 = le->tail1; nl = t0 == kHole ? 0 : (t1 == kHole ? 1 : 2); }
+        if (j >= 0) { const su4 q = sq[j]; nl = q.z & 0xFFFFu; t0 = q.y >> 16; t1 = q.y & 0xFFFFu; }
+        else if (le) {
+            const su2 q = lq[1];
+            t1 = q.x; t0 = q.y; nl = t0 == kHole ? 0 : (t1 == kHole ? 1 : 2);
+        }
         else break;
         if (nl == 0) continue;
         if (need == 2) { h.p1 = t0; need = 1; if (nl >= 2) { h.p2 = t1; need = 0; } }
@@ -525,8 +538,11 @@ __device__ Halo halo_slow(const TileSum *sin, uint32_t n_tiles, uint32_t tile, c
     need = 2;
     for (int64_t j = (int64_t)tile + 1; need && j <= (int64_t)n_tiles; ++j) {
         uint32_t nl, t0, t1;
-        if (j < (int64_t)n_tiles) { TileSum s = sin[j]; nl = s.n_live; t0 = s.head0; t1 = s.head1; }
-        else if (re) { t0 = re->head0; t1 = re->head1; nl = t0 == kHole ? 0 : (t1 == kHole ? 1 : 2); }
+        if (j < (int64_t)n_tiles) { const su4 q = sq[j]; nl = q.z & 0xFFFFu; t0 = q.x & 0xFFFFu; t1 = q.x >> 16; }
+        else if (re) {
+            const su2 q = rq[0];
+            t0 = q.x; t1 = q.y; nl = t0 == kHole ? 0 : (t1 == kHole ? 1 : 2);
+        }
         else break;
         if (nl == 0) continue;
         if (need == 2) { h.n1 = t0; need = 1; if (nl >= 2) { h.n2 = t1; need = 0; } }
@@ -849,6 +865,13 @@ struct TileIn {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#define MBPE_GLOBAL_AS __attribute__((address_space(1)))
+// a wave-uniform address, pinned to scalar registers
+__device__ __forceinline__ uintptr_t uniform_ptr(uintptr_t p) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return ((uintptr_t)hi << 32) | lo;
+}
+
 // Both loads are unconditional: a branch around a load makes hipcc wait
 // vmcnt(0) at the next use, which would drain the tiles prefetched behind
 // this one.  The three summaries come through a bounds-checked buffer load of
@@ -859,7 +882,11 @@ __device__ __forceinline__ TileIn tile_issue(const uint16_t *tok, __amdgpu_buffe
                                              uint32_t tile) {
     TileIn t;
     const uint32_t lane = lane_id();
-    t.q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kWave + lane];
+    // (uniform 64-bit base + 32-bit lane offset: the address then needs one VGPR, not a pair per buffer)
+    const MBPE_GLOBAL_AS char *base =
+        (const MBPE_GLOBAL_AS char *)uniform_ptr(reinterpret_cast<uintptr_t>(tok) + (uint64_t)tile * (kWave * 16u));
+    const u32x4 q = *(const MBPE_GLOBAL_AS u32x4 *)(base + lane * 16u);
+    t.q = make_uint4(q.x, q.y, q.z, q.w);
     const uint32_t j = tile + (lane >> 2) - 1u;                // tile 0, lanes 0..3 wrap to 0xFFFFFFFF
     const uint32_t off = (lane < 12 && j < 0x0FFFFFFFu) ? j * 16u + (lane & 3u) * 4u : 0xFFFFFFF0u;
     t.smw = __builtin_amdgcn_raw_buffer_load_b32(sums_rsrc, off, 0, 0);
@@ -1215,13 +1242,27 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 // bucket within its two keys: a candidate that would be the third key of a
 // bucket ends the batch.  0xFFFE is never a token id (MBPE_MAX_VOCAB_*), so
 // kEmptyPair can never be asked for.
-constexpr uint32_t kBuckets = 2048;
+#ifndef MBPE_LUT_KEYS
+#define MBPE_LUT_KEYS 2
+#endif
+constexpr uint32_t kBucketKeys = MBPE_LUT_KEYS;          // keys per bucket: 2 (8-byte read) or 4 (16-byte read)
+#ifndef MBPE_LUT_BUCKETS
+#define MBPE_LUT_BUCKETS (8192 / MBPE_LUT_KEYS)
+#endif
+constexpr uint32_t kBuckets = MBPE_LUT_BUCKETS;
+static_assert((kBuckets & (kBuckets - 1u)) == 0, "the hash is masked");
 constexpr uint32_t kEmptyPair = 0xFFFEFFFEu;
+static_assert(kBucketKeys == 2 || kBucketKeys == 4, "bucket = one 8- or 16-byte LDS read");
 
 static_assert(kBatchMax <= 256, "batch indices are stored in bytes");
 struct BatchLut {
+#if MBPE_LUT_KEYS == 2
     uint2 bucket[kBuckets];
     uint16_t bidx[kBuckets];     // batch index of bucket.x (low byte) and bucket.y (high byte)
+#else
+    uint4 bucket[kBuckets];
+    uint32_t bidx[kBuckets];     // batch indices of bucket.x .. bucket.w, one byte each
+#endif
 };
 
 __device__ __forceinline__ uint32_t pair_hash(uint32_t first, uint32_t second) {
@@ -1229,10 +1270,9 @@ __device__ __forceinline__ uint32_t pair_hash(uint32_t first, uint32_t second) {
 }
 
 __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys, uint32_t fake) {
-    for (uint32_t i = threadIdx.x; i < kBuckets; i += blockDim.x) {
-        lut.bucket[i] = make_uint2(kEmptyPair, kEmptyPair);
-        lut.bidx[i] = 0;
-    }
+    uint32_t *words = reinterpret_cast<uint32_t *>(lut.bucket);
+    for (uint32_t i = threadIdx.x; i < kBuckets * kBucketKeys; i += blockDim.x) words[i] = kEmptyPair;
+    for (uint32_t i = threadIdx.x; i < kBuckets; i += blockDim.x) lut.bidx[i] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
         for (uint32_t j = 0; j < n_keys; ++j) {
@@ -1241,8 +1281,10 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
             const uint32_t b = (key & 0xFFFFu) == a ? fake : key & 0xFFFFu;     // (t,t): see tt_rename
             const uint32_t h = pair_hash(a, b);
             const uint32_t kk = a | (b << 16);
-            if (lut.bucket[h].x == kEmptyPair) { lut.bucket[h].x = kk; lut.bidx[h] = (uint16_t)j; }
-            else { lut.bucket[h].y = kk; lut.bidx[h] = (uint16_t)(lut.bidx[h] | (j << 8)); }
+            uint32_t r = 0;                       // first free key of the bucket (selection keeps it within kBucketKeys)
+            while (r + 1 < kBucketKeys && words[h * kBucketKeys + r] != kEmptyPair) ++r;
+            words[h * kBucketKeys + r] = kk;
+            lut.bidx[h] = (decltype(lut.bidx[0] + 0))(lut.bidx[h] | (j << (8u * r)));
         }
     }
     __syncthreads();
@@ -1251,9 +1293,13 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
 // is (first, second) a batch pair?  first may be any raw slot value (a hole or a
 // token with the chunk-end bit never matches), second the id of the next live token
 __device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, uint32_t second) {
-    const uint2 bk = lut.bucket[pair_hash(first, second)];
+    const auto bk = lut.bucket[pair_hash(first, second)];
     const uint32_t kk = first | (second << 16);
+#if MBPE_LUT_KEYS == 2
     return bk.x == kk || bk.y == kk;
+#else
+    return bk.x == kk || bk.y == kk || bk.z == kk || bk.w == kk;
+#endif
 }
 
 // The same test in the streaming loops, written so that it costs few VALU instructions:
@@ -1262,17 +1308,44 @@ __device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, u
 __device__ __forceinline__ uint32_t pair_miss(const BatchLut &lut, uint32_t first, uint32_t second) {
     uint32_t h;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(2531u), "v"(first));
-    const uint2 bk = lut.bucket[h & (kBuckets - 1u)];
+    const auto bk = lut.bucket[h & (kBuckets - 1u)];
     const uint32_t kk = first | (second << 16);
     const uint32_t dx = bk.x ^ kk, dy = bk.y ^ kk;
-    return dx < dy ? dx : dy;
+    uint32_t d = dx < dy ? dx : dy;
+#if MBPE_LUT_KEYS == 4
+    const uint32_t dz = bk.z ^ kk, dw = bk.w ^ kk;
+    const uint32_t e = dz < dw ? dz : dw;
+    d = d < e ? d : e;
+#endif
+    return d;
+}
+
+// ... and as a per-lane boolean, which the compiler keeps as a wave mask in scalar registers: one
+// compare per key, and the results combine on the scalar unit.
+__device__ __forceinline__ bool pair_hit(const BatchLut &lut, uint32_t first, uint32_t second) {
+    uint32_t h;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(2531u), "v"(first));
+    const auto bk = lut.bucket[h & (kBuckets - 1u)];
+    const uint32_t kk = first | (second << 16);
+#if MBPE_LUT_KEYS == 2
+    return bk.x == kk || bk.y == kk;
+#else
+    return bk.x == kk || bk.y == kk || bk.z == kk || bk.w == kk;
+#endif
 }
 
 // index of the pair (only called for pairs that passed pair_test)
 __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, uint32_t second) {
     const uint32_t h = pair_hash(first, second);
     const uint32_t ix = lut.bidx[h];
-    return (int)(lut.bucket[h].x == (first | (second << 16)) ? ix & 0xFFu : ix >> 8);
+    const uint32_t kk = first | (second << 16);
+#if MBPE_LUT_KEYS == 2
+    return (int)(lut.bucket[h].x == kk ? ix & 0xFFu : ix >> 8);
+#else
+    const uint4 bk = lut.bucket[h];
+    const uint32_t r = bk.x == kk ? 0u : bk.y == kk ? 8u : bk.z == kk ? 16u : 24u;
+    return (int)((ix >> r) & 0xFFu);
+#endif
 }
 
 // Which pass merges a multi-pair batch: the fused one (reads the stream once, writes all of it to
@@ -1391,7 +1464,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
                 conflict |= (b == ai) || (a == bi);
                 same_bucket += pair_hash(ai, bi) == pair_hash(a, b);
             }
-            if (conflict || same_bucket >= 2) {           // (a lookup bucket holds two keys)
+            if (conflict || same_bucket >= kBucketKeys) {       // (a lookup bucket holds kBucketKeys keys)
                 if (tid == 0) { if (conflict) ctl->cut_conflict += 1; else ctl->cut_bucket += 1; }
                 break;
             }
@@ -1639,7 +1712,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                     ++n_skip;
                     continue;
                 }
-                if (conf != 0ull || same >= 2) { cut = conf ? 1u : 2u; break; }
+                if (conf != 0ull || same >= kBucketKeys) { cut = conf ? 1u : 2u; break; }
             }
 #pragma unroll
             for (int r = 0; r < kPer; ++r)
@@ -1981,7 +2054,10 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, uint32_t tt
                                                  DeltaCache &dc, bool dc_on, uint32_t &wave_rm) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
-    const uint32_t lane = lane_id();
+    // (an opaque copy of the lane id: the 64-bit lane masks below are cheaper to rebuild per tile than
+    //  to keep in registers across the streaming loop, where the compiler would spill them)
+    uint32_t lane = lane_id();
+    asm volatile("" : "+v"(lane));
     const unsigned long long lane_bit = 1ull << lane;
     uint32_t Lm = 0;
 #pragma unroll
@@ -2089,8 +2165,11 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, uint32_t tt
 
 // (7 waves per SIMD: the cold instantiation meets it with two spilled registers, which is cheaper than
 //  running with 6 waves; 8 would spill ten and is slower.  The delta cache of the HOT one allows 5.)
+#ifndef MBPE_FUSED_WAVES
+#define MBPE_FUSED_WAVES 4
+#endif
 template <bool CHUNKED, bool HOT, bool TT, int DIAG = 0>
-__global__ __launch_bounds__(kMergeThreads, HOT ? 5 : 7) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
+__global__ __launch_bounds__(kMergeThreads, MBPE_FUSED_WAVES) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
                                                                const TileSum *__restrict__ sin,
                                                                TileSum *__restrict__ sout, uint32_t n_tiles,
                                                                uint32_t *__restrict__ chg, const BatchState *bs,
@@ -2157,24 +2236,26 @@ __global__ __launch_bounds__(kMergeThreads, HOT ? 5 : 7) void k_fused_batch(uint
             const uint32_t c_init = hi ? nf : h.n1;
             uint32_t c = c_init;
             uint32_t cj[8];
-            uint32_t nohit = 0;          // bit j clear <=> slot j starts a match
+            uint32_t Am = 0;             // bit j: slot j starts a match
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
                 cj[j] = c;
-                const uint32_t d = pair_miss(lut, s[j], c & idmask);
-                nohit = (nohit << 1) | (d < 1u ? d : 1u);
+                const bool hit = pair_hit(lut, s[j], CHUNKED ? c & idmask : c);     // (ids are 16-bit: no mask needed)
+                Am = Am + Am + (hit ? 1u : 0u);         // one add-with-carry, the carry being the compare mask
                 c = s[j] != kHole ? s[j] : c;
             }
-            const bool any = nohit != 0xFFu;
+            const bool any = Am != 0u;
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
-                const uint32_t Am = nohit ^ 0xFFu;
                 outq = fused_tile_full<CHUNKED, DIAG>(t0.q, tt_tok, tt_idx, lane_tt, s, cj, Am, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
                                                 wave_rm);
             }
         }
-        reinterpret_cast<uint4 *>(dst)[(uint64_t)tile * kWave + lane] = outq;
+        MBPE_GLOBAL_AS char *obase =
+            (MBPE_GLOBAL_AS char *)uniform_ptr(reinterpret_cast<uintptr_t>(dst) + (uint64_t)tile * (kWave * 16u));
+        u32x4 oq; oq.x = outq.x; oq.y = outq.y; oq.z = outq.z; oq.w = outq.w;
+        *(MBPE_GLOBAL_AS u32x4 *)(obase + lane * 16u) = oq;
 
         if (!v1) break;
         tile += n_waves;

@@ -121,7 +121,10 @@ struct DevCtl {
 
 // A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
 // stream (see k_select_batch).  Per batch scratch, device memory:
-constexpr int kBatchMax = 128;
+#ifndef MBPE_BATCH_MAX
+#define MBPE_BATCH_MAX 256
+#endif
+constexpr int kBatchMax = MBPE_BATCH_MAX;
 // candidates gathered by k_sel_scan
 constexpr uint32_t kSelCap = 2048;
 struct SelList {

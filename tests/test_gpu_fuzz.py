@@ -38,7 +38,7 @@ def _case(rng, text):
         cuts = np.unique(rng.integers(1, len(data), size=max(len(data) // int(rng.integers(2, 200)), 1)))
         off = np.concatenate([[0], cuts, [len(data)]]).astype(np.uint64)
     vocab = 256 + int(rng.integers(0, 400))
-    opts = {"max_batch": int(rng.choice([1, 2, 3, 7, 16, 64, 128])), "fused_min": int(rng.choice([2, 24, 1000])),
+    opts = {"max_batch": int(rng.choice([1, 2, 3, 7, 16, 64, 128, 256])), "fused_min": int(rng.choice([2, 24, 1000])),
             "dense_table": int(rng.choice([0, 1])), "threshold_select": int(rng.choice([0, 1])),
             "compact_den": int(rng.choice([0, 2, 8])), "batch": int(rng.choice([1, 3, 64])),
             "multi_merge": int(rng.choice([0, 1, 1, 1]))}

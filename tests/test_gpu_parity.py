@@ -369,7 +369,7 @@ def test_tie_heavy_text_large_vocab(tr, chunked):
     base = read_data("shakespeare.txt")[:150000]
     data = (base + b"\n") * 16
     off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data) if chunked else None
-    vocab = 256 + (2500 if chunked else 4000)
+    vocab = 256 + (2500 if chunked else 6000)
     want_m, want_c = O.train(data, vocab, off)
     m, c, st = tr.train_lexical(data, vocab, off)
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
