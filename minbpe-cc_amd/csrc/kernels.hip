@@ -865,6 +865,16 @@ struct TileIn {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// whole-wave shifts by one lane (DPP): lane i takes lane i+1 / lane i-1, the last / first lane takes `edge`
+__device__ __forceinline__ uint32_t wave_from_next(uint32_t v, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false);     // wave_shl:1
+}
+__device__ __forceinline__ uint32_t wave_from_prev(uint32_t v, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false);     // wave_shr:1
+}
+// this lane's bit of a wave mask, as a condition (one v_cndmask at the use, no 64-bit lane arithmetic)
+__device__ __forceinline__ bool lane_of(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
 #define MBPE_GLOBAL_AS __attribute__((address_space(1)))
 // a wave-uniform address, pinned to scalar registers
 __device__ __forceinline__ uintptr_t uniform_ptr(uintptr_t p) {
@@ -2070,14 +2080,14 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, uint32_t tt
     const unsigned long long G = __ballot(lastA);
     const bool tcin = pair_test(lut, h.p1, tile_first & idmask);          // uniform
     const unsigned long long CIN = (((G << 1) | (tcin ? 1ull : 0ull)) + E) & m_live;
-    const uint32_t cin = (CIN & lane_bit) != 0ull ? 1u : 0u;
+    const uint32_t cin = lane_of(CIN) ? 1u : 0u;
     const uint32_t Bm = (((Am << 1) | cin) + Hm) & Lm;
     // the same for "the last live token before this lane ends a match"
     const bool lastB = Bm > (Lm & ~Bm);
     const unsigned long long GB = __ballot(lastB);
     const bool tbin = h.p2 != kHole && pair_test(lut, h.p2, h.p1 & idmask);   // uniform
     const unsigned long long BIN = (((GB << 1) | (tbin ? 1ull : 0ull)) + E) & m_live;
-    const uint32_t bin = (BIN & lane_bit) != 0ull ? 1u : 0u;
+    const uint32_t bin = lane_of(BIN) ? 1u : 0u;
     const uint32_t touch = Am & ((((Bm << 1) | bin) + Hm) & Lm);     // starts a match right after another one
 
     const unsigned long long ab = __ballot((Am | Bm) != 0u);
@@ -2089,11 +2099,19 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, uint32_t tt
     for (int j = 0; j < 8; ++j) ll = s[j] != kHole ? s[j] : ll;
     uint32_t lastj = 0;
     if (lastA) lastj = (uint32_t)lut_index(lut, ll, c_init & idmask);
-    const unsigned long long lo = m_live & (lane_bit - 1ull);
-    const uint32_t src = lo ? 63u - (uint32_t)__builtin_clzll(lo) : lane;
-    const uint32_t got = __shfl(ll | (lastj << 16), src, kWave);
-    uint32_t p1 = lo ? (got & 0xFFFFu) : h.p1;
-    uint32_t pj = lo ? (got >> 16) : (tcin ? (uint32_t)lut_index(lut, h.p1, tile_first & idmask) : 0u);
+    uint32_t p1, pj;
+    const uint32_t pj_tile = tcin ? (uint32_t)lut_index(lut, h.p1, tile_first & idmask) : 0u;     // uniform
+    if (m_live == ~0ull) {                   // the previous lane is the previous live lane
+        const uint32_t got = wave_from_prev(ll | (lastj << 16), h.p1 | (pj_tile << 16));
+        p1 = got & 0xFFFFu;
+        pj = got >> 16;
+    } else {
+        const unsigned long long lo = m_live & (lane_bit - 1ull);
+        const uint32_t src = lo ? 63u - (uint32_t)__builtin_clzll(lo) : lane;
+        const uint32_t got = __shfl(ll | (lastj << 16), src, kWave);
+        p1 = lo ? (got & 0xFFFFu) : h.p1;
+        pj = lo ? (got >> 16) : pj_tile;
+    }
     uint32_t pjb = 0;
     // rare: the token before this lane ends a match and this lane's first live token starts one
     if (__ballot(bin != 0u && (Am & Lm & (0u - Lm)) != 0u) != 0ull) {
@@ -2231,9 +2249,14 @@ __global__ __launch_bounds__(kMergeThreads, MBPE_FUSED_WAVES) void k_fused_batch
 #pragma unroll
             for (int j = 7; j >= 0; --j) lf = s[j] != kHole ? s[j] : lf;
             const unsigned long long m_live = __ballot(lf != kHole);
-            const unsigned long long hi = m_live & gt_mask;
-            const uint32_t nf = __shfl(lf, hi ? (uint32_t)__builtin_ctzll(hi) : lane, kWave);
-            const uint32_t c_init = hi ? nf : h.n1;
+            uint32_t c_init;
+            if (m_live == ~0ull) {               // every lane holds a live token (nearly always): the next lane's
+                c_init = wave_from_next(lf, h.n1);
+            } else {
+                const unsigned long long hi = m_live & gt_mask;
+                const uint32_t nf = __shfl(lf, hi ? (uint32_t)__builtin_ctzll(hi) : lane, kWave);
+                c_init = hi ? nf : h.n1;
+            }
             uint32_t c = c_init;
             uint32_t cj[8];
             uint32_t Am = 0;             // bit j: slot j starts a match
