@@ -184,7 +184,7 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *   "compact_den"   compact when holes * den >= slots (default 16; 0 = never)
  *   "batch"         sequences (or single merges) per host round trip (default 64)
  *   "multi_merge"   1 = several independent merges per stream pass (default), 0 = one
- *   "max_batch"     most merges one pass may take (default and limit 128)
+ *   "max_batch"     most merges one pass may take (default and limit 512)
  *   "fused_min"     batches of at least this many pairs read the stream once and write
  *                   the merged stream to the second buffer (default 24; frequent pairs
  *                   qualify earlier); 2 = every multi-pair batch, >= 1000 = never
@@ -192,6 +192,8 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *                   0 = always the hashed pair table
  *   "threshold_select" 1 = choose batches from a gathered, sorted candidate list
  *                   (default), 0 = always walk the argmax bounds pair by pair
+ *   "sel_cap"       capacity of the candidate list of the threshold selection (default and
+ *                   limit 4096, at least 64; tests lower it to force the overflow path)
  *   "hier_argmax"   -1 auto / 0 scan every entry / 1 walk the block bounds
  *                   (single-merge mode)
  *   "force_exchange" 1 = take the multi-rank path (rank edges, exchange) even

@@ -1257,21 +1257,21 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 #endif
 constexpr uint32_t kBucketKeys = MBPE_LUT_KEYS;          // keys per bucket: 2 (8-byte read) or 4 (16-byte read)
 #ifndef MBPE_LUT_BUCKETS
-#define MBPE_LUT_BUCKETS (8192 / MBPE_LUT_KEYS)
+#define MBPE_LUT_BUCKETS (8192 / MBPE_LUT_KEYS)      /* 4096 buckets of two keys: 32 KB + 16 KB of indices */
 #endif
 constexpr uint32_t kBuckets = MBPE_LUT_BUCKETS;
 static_assert((kBuckets & (kBuckets - 1u)) == 0, "the hash is masked");
 constexpr uint32_t kEmptyPair = 0xFFFEFFFEu;
 static_assert(kBucketKeys == 2 || kBucketKeys == 4, "bucket = one 8- or 16-byte LDS read");
 
-static_assert(kBatchMax <= 256, "batch indices are stored in bytes");
+static_assert(kBatchMax <= 65536, "batch indices are stored in 16 bits");
 struct BatchLut {
 #if MBPE_LUT_KEYS == 2
     uint2 bucket[kBuckets];
-    uint16_t bidx[kBuckets];     // batch index of bucket.x (low byte) and bucket.y (high byte)
+    uint32_t bidx[kBuckets];     // batch index of bucket.x (low half) and bucket.y (high half)
 #else
     uint4 bucket[kBuckets];
-    uint32_t bidx[kBuckets];     // batch indices of bucket.x .. bucket.w, one byte each
+    uint2 bidx[kBuckets];        // batch indices of bucket.x .. bucket.w, 16 bits each
 #endif
 };
 
@@ -1282,7 +1282,8 @@ __device__ __forceinline__ uint32_t pair_hash(uint32_t first, uint32_t second) {
 __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys, uint32_t fake) {
     uint32_t *words = reinterpret_cast<uint32_t *>(lut.bucket);
     for (uint32_t i = threadIdx.x; i < kBuckets * kBucketKeys; i += blockDim.x) words[i] = kEmptyPair;
-    for (uint32_t i = threadIdx.x; i < kBuckets; i += blockDim.x) lut.bidx[i] = 0;
+    uint32_t *iw = reinterpret_cast<uint32_t *>(lut.bidx);
+    for (uint32_t i = threadIdx.x; i < kBuckets * kBucketKeys / 2; i += blockDim.x) iw[i] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
         for (uint32_t j = 0; j < n_keys; ++j) {
@@ -1294,7 +1295,8 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
             uint32_t r = 0;                       // first free key of the bucket (selection keeps it within kBucketKeys)
             while (r + 1 < kBucketKeys && words[h * kBucketKeys + r] != kEmptyPair) ++r;
             words[h * kBucketKeys + r] = kk;
-            lut.bidx[h] = (decltype(lut.bidx[0] + 0))(lut.bidx[h] | (j << (8u * r)));
+            uint16_t *ix = reinterpret_cast<uint16_t *>(&lut.bidx[h]);
+            ix[r] = (uint16_t)j;
         }
     }
     __syncthreads();
@@ -1347,14 +1349,17 @@ __device__ __forceinline__ bool pair_hit(const BatchLut &lut, uint32_t first, ui
 // index of the pair (only called for pairs that passed pair_test)
 __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, uint32_t second) {
     const uint32_t h = pair_hash(first, second);
+#if MBPE_LUT_KEYS == 2
     const uint32_t ix = lut.bidx[h];
+#endif
     const uint32_t kk = first | (second << 16);
 #if MBPE_LUT_KEYS == 2
-    return (int)(lut.bucket[h].x == kk ? ix & 0xFFu : ix >> 8);
+    return (int)(lut.bucket[h].x == kk ? ix & 0xFFFFu : ix >> 16);
 #else
     const uint4 bk = lut.bucket[h];
-    const uint32_t r = bk.x == kk ? 0u : bk.y == kk ? 8u : bk.z == kk ? 16u : 24u;
-    return (int)((ix >> r) & 0xFFu);
+    const uint2 i2 = lut.bidx[h];
+    const uint32_t w = (bk.x == kk || bk.y == kk) ? i2.x : i2.y;
+    return (int)((bk.x == kk || bk.z == kk) ? w & 0xFFFFu : w >> 16);
 #endif
 }
 
@@ -1519,7 +1524,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
 // all gathered ones.  T only decides how many candidates come back; k_sel_pick adapts it, and
 // leaves the batch to k_select_batch when the list is empty or overflowed.
 
-__global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelList *sel, uint32_t n_target,
+__global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelList *sel, uint32_t n_target, uint32_t sel_cap,
                                                   int attempt) {
     if (attempt > 0 && (ctl->sel_ok || !ctl->sel_retry)) return;
     const unsigned long long T = ctl->sel_T;
@@ -1539,7 +1544,7 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
         // far more entries than the list holds: no point in reading on, k_sel_pick will look for a
         // better threshold among the block bounds
         if (!bounds_only &&
-            __hip_atomic_load(&ctl->sel_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4u * kSelCap) break;
+            __hip_atomic_load(&ctl->sel_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4u * sel_cap) break;
         const uint64_t B64 = (step * kWave + lane) * n_waves + wave;
         const uint32_t B = (uint32_t)B64;
         const unsigned long long bound = B64 < n_blocks
@@ -1551,12 +1556,12 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
                 uint32_t at = 0;
                 if (lane == 0) at = atomicAdd(&ctl->sel_n, (uint32_t)__popcll(todo));
                 at = rfl(at) + (uint32_t)__popcll(todo & lt_mask);
-                if (bound >= T && at < kSelCap) { sel->packed[at] = bound; sel->eidx[at] = B; }
+                if (bound >= T && at < sel_cap) { sel->packed[at] = bound; sel->eidx[at] = B; }
             }
             continue;
         }
         while (todo) {
-            if (__hip_atomic_load(&ctl->sel_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4u * kSelCap) break;
+            if (__hip_atomic_load(&ctl->sel_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4u * sel_cap) break;
             const uint32_t b = (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1ull;
             const uint32_t blk = (uint32_t)((step * kWave + b) * n_waves + wave);
@@ -1578,7 +1583,7 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
                     uint32_t at = 0;
                     if (lane == 0) at = atomicAdd(&ctl->sel_n, (uint32_t)__popcll(hit));
                     at = rfl(at) + (uint32_t)__popcll(hit & lt_mask);
-                    if (p >= T && p != 0ull && at < kSelCap) { sel->packed[at] = p; sel->eidx[at] = e; }
+                    if (p >= T && p != 0ull && at < sel_cap) { sel->packed[at] = p; sel->eidx[at] = e; }
                 }
             }
             mx = wave_max_u64(mx);
@@ -1594,7 +1599,7 @@ constexpr int kPickThreads = 1024;
 __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchState *bs, const SelList *sel,
                                                            unsigned long long *best, uint32_t n_target,
                                                            uint32_t max_batch, uint32_t fused_min,
-                                                           uint32_t n_ranks, int attempt, uint32_t fake_id) {
+                                                           uint32_t n_ranks, int attempt, uint32_t fake_id, uint32_t sel_cap) {
     __shared__ unsigned long long sp[kSelCap];
     __shared__ uint32_t si[kSelCap];
     const uint32_t tid = threadIdx.x;
@@ -1621,7 +1626,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         }
         return;
     }
-    const uint32_t n_l = n_all < kSelCap ? n_all : kSelCap;
+    const uint32_t n_l = n_all < sel_cap ? n_all : sel_cap;
     uint32_t n_sort = 64;                       // power of two >= n_l
     while (n_sort < n_l) n_sort <<= 1;
     for (uint32_t i = tid; i < n_sort; i += kPickThreads) {
@@ -1654,8 +1659,8 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         // enough entries; the third attempt gathers them.
         if (tid == 0 && attempt < 2) {
             unsigned long long r = 3ull * (adapt < 32u ? 32u : adapt);     // blocks; each holds >= 1 entry, often several
-            if (r > kSelCap / 4) r = kSelCap / 4;
-            if (n_all > kSelCap) r = (unsigned long long)kSelCap * r / n_all;
+            if (r > sel_cap / 4) r = sel_cap / 4;
+            if (n_all > sel_cap) r = (unsigned long long)sel_cap * r / n_all;
             r = r < 1 ? 1 : r;
             if (r > n_l - 1) r = n_l - 1;
             ctl->sel_T = sp[r];
@@ -1663,7 +1668,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         }
         return;
     }
-    if (n_all > kSelCap) {
+    if (n_all > sel_cap) {
         if (tid == 0 && attempt == 0) {       // overflow: look at the block bounds next
             ctl->sel_mode = 1;
             ctl->sel_retry = 1;
@@ -1945,7 +1950,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
 }
 
 template <bool CHUNKED, bool HOT, bool TT, int DIAG = 0>
-__global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *tok0, const uint16_t *tok1,
+__global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0, const uint16_t *tok1,
                                                               const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                               uint32_t *__restrict__ chg, const BatchState *bs,
                                                               uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
@@ -1955,7 +1960,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_scan_batch(const uint16_t *to
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     __shared__ BatchLut lut;
     const uint32_t lane = lane_id();
-    const uint32_t waves_per_block = kMergeThreads / kWave;
+    const uint32_t waves_per_block = kLutThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
     __shared__ DeltaCache dc;
     const uint32_t n_keys = ctl->batch_n;
@@ -2187,7 +2192,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, uint32_t tt
 #define MBPE_FUSED_WAVES 4
 #endif
 template <bool CHUNKED, bool HOT, bool TT, int DIAG = 0>
-__global__ __launch_bounds__(kMergeThreads, MBPE_FUSED_WAVES) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
+__global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
                                                                const TileSum *__restrict__ sin,
                                                                TileSum *__restrict__ sout, uint32_t n_tiles,
                                                                uint32_t *__restrict__ chg, const BatchState *bs,
@@ -2197,7 +2202,7 @@ __global__ __launch_bounds__(kMergeThreads, MBPE_FUSED_WAVES) void k_fused_batch
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     __shared__ BatchLut lut;
     const uint32_t lane = lane_id();
-    const uint32_t waves_per_block = kMergeThreads / kWave;
+    const uint32_t waves_per_block = kLutThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
     __shared__ DeltaCache dc;
     const uint32_t n_keys = ctl->batch_n;
@@ -2341,10 +2346,11 @@ __global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, con
 // How many pairs of the batch the sequential algorithm would really have chosen in this order
 // (see above).  Then the deltas of the surviving prefix are made exact for "only the prefix is
 // merged", and the argmax bounds of the dropped pairs are restored.
-__global__ __launch_bounds__(256) void k_validate(PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m,
-                                                  uint32_t *hdr_adj, uint32_t *LR) {
-    static_assert(kBatchMax <= 256, "one workgroup of 256 threads validates a batch");
-    __shared__ unsigned long long s_run[256];
+constexpr int kValThreads = kBatchMax < 256 ? 256 : kBatchMax;
+__global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m,
+                                                          uint32_t *hdr_adj, uint32_t *LR) {
+    static_assert(kBatchMax <= 1024, "one workgroup validates a batch, a thread per pair");
+    __shared__ unsigned long long s_run[kValThreads];
     __shared__ uint32_t s_commit;
     const uint32_t tid = threadIdx.x;
     const uint32_t n = ctl->batch_n;
@@ -2364,7 +2370,7 @@ __global__ __launch_bounds__(256) void k_validate(PairTable t, DevCtl *ctl, Batc
         atomicMax(&s_run[p], pack_best((int32_t)bs->adj_out[p], ((X0 + p) << 16) | aq));         // (X_p, a_q), q not merged
     }
     __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {        // inclusive prefix maximum
+    for (uint32_t d = 1; d < (uint32_t)kValThreads; d <<= 1) {        // inclusive prefix maximum
         const unsigned long long o = tid >= d ? s_run[tid - d] : 0ull;
         __syncthreads();
         if (o > s_run[tid]) s_run[tid] = o;
@@ -2616,7 +2622,7 @@ __global__ void k_list_marked(const uint32_t *__restrict__ chg, uint32_t n_words
 }
 
 template <bool CHUNKED, bool TT>
-__global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *tok0, uint16_t *tok1,
+__global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, uint16_t *tok1,
                                                                   const TileSum *__restrict__ sin,
                                                                   TileSum *__restrict__ sout, uint32_t n_tiles,
                                                                   uint32_t *__restrict__ chg,
@@ -2636,7 +2642,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_rewrite_marked(uint16_t *tok0
     const uint32_t n_list = ctl->n_marked;
     lut_build(lut, bs, n_keys, idmask - 1u);
     const uint32_t lane = lane_id();
-    const uint32_t waves_per_block = kMergeThreads / kWave;
+    const uint32_t waves_per_block = kLutThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
     uint32_t i = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     if (i >= n_list) return;
@@ -2962,16 +2968,16 @@ inline int blocks_for(uint64_t n, int threads, int max_blocks) {
 // workgroups of a kernel that fit one CU at a time (registers, LDS): the strided tile loops
 // want exactly one resident "round" of workgroups, a second partial round would idle CUs
 template <typename K>
-inline int resident_blocks(K kernel) {
+inline int resident_blocks(K kernel, int threads = kMergeThreads) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kMergeThreads, 0) != hipSuccess || n < 1) n = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) n = 1024 / threads;
     return n > 8 ? 8 : n;
 }
 
 // grid for the wave-per-tile kernels: enough waves to fill the chip (8 blocks
 // of 4 waves per CU), fewer when the stream is short
-inline int tile_grid(uint32_t n_tiles, int n_cus, int blocks_per_cu = 8) {
-    const uint32_t waves_per_block = kMergeThreads / kWave;
+inline int tile_grid(uint32_t n_tiles, int n_cus, int blocks_per_cu = 8, int threads = kMergeThreads) {
+    const uint32_t waves_per_block = threads / kWave;
     uint64_t blocks = ((uint64_t)n_tiles + waves_per_block - 1) / waves_per_block;
     const uint64_t cap = (uint64_t)(n_cus > 0 ? n_cus : 256) * blocks_per_cu;
     if (blocks > cap) blocks = cap;
@@ -3102,14 +3108,16 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus, int n_ranks, uint32_t endbit) {
+                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap) {
     const uint32_t fake_id = (endbit ? 0x7FFFu : 0xFFFFu) - 1u;      // see tt_rename
+    if (sel_cap < 64u) sel_cap = 64u;
+    if (sel_cap > kSelCap) sel_cap = kSelCap;
     if (sel) {
         const int blocks = (n_cus > 0 ? n_cus : 256) * 4;
         for (int attempt = 0; attempt < 3; ++attempt) {
-            hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target, attempt);
+            hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target, sel_cap, attempt);
             hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
-                               fused_min, (uint32_t)n_ranks, attempt, fake_id);
+                               fused_min, (uint32_t)n_ranks, attempt, fake_id, sel_cap);
         }
     }
     hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch,
@@ -3121,8 +3129,9 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
                         int n_cus, uint32_t *hdr_m, const uint32_t *run_in) {
     if (!n_tiles) return;
-    static const int occ_c = resident_blocks(k_fused_batch<true, false, false, 0>), occ_b = resident_blocks(k_fused_batch<false, false, false, 0>);
-    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
+    static const int occ_c = resident_blocks(k_fused_batch<true, false, false, 0>, kLutThreads),
+                     occ_b = resident_blocks(k_fused_batch<false, false, false, 0>, kLutThreads);
+    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kLutThreads);
 #ifdef MBPE_DIAG
     const int diag = getenv("MBPE_FUSED_DIAG") ? atoi(getenv("MBPE_FUSED_DIAG")) : 0;   // (re-read: set after warm-up)
     if (diag == 2 && !endbit) {
@@ -3157,9 +3166,9 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
                        const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
                        int n_cus, const uint32_t *run_in) {
     if (!n_tiles) return;
-    static const int occ_c = resident_blocks(k_scan_batch<true, false, false, 0>),
-                     occ_b = resident_blocks(k_scan_batch<false, false, false, 0>);
-    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
+    static const int occ_c = resident_blocks(k_scan_batch<true, false, false, 0>, kLutThreads),
+                     occ_b = resident_blocks(k_scan_batch<false, false, false, 0>, kLutThreads);
+    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kLutThreads);
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_SCAN_DIAG") ? atoi(getenv("MBPE_SCAN_DIAG")) : 0;
     if (diag == 1 && !endbit) {
@@ -3213,7 +3222,7 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     if (blocks < 2) blocks = 2;
     hipLaunchKernelGGL(k_adj_sums, dim3(1), dim3(kBatchMax), 0, s, hdr_adj, bs, ctl);
     hipLaunchKernelGGL(k_delta_max, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, LR, bs, ctl);
-    hipLaunchKernelGGL(k_validate, dim3(1), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
+    hipLaunchKernelGGL(k_validate, dim3(1), dim3(kValThreads), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     if (t.cells) {
         uint32_t grid = ((id_upper + kApplyTile - 1) / kApplyTile) * (kBatchMax / kApplyTile);
         const uint32_t need = (kBatchMax * kBatchMax + 255) / 256;          // the ADJ cells, one thread each
@@ -3231,7 +3240,9 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok, uint16_t *tok1, const T
     if (!n_tiles) return;
     const uint32_t n_words = (n_tiles + 31u) / 32u;
     hipLaunchKernelGGL(k_list_marked, dim3((n_words + 255) / 256), dim3(256), 0, s, chg, n_words, list, ctl);
-    const dim3 grid(tile_grid(n_tiles, n_cus)), block(kMergeThreads);
+    static const int occ_c = resident_blocks(k_rewrite_marked<true, false>, kLutThreads),
+                     occ_b = resident_blocks(k_rewrite_marked<false, false>, kLutThreads);
+    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kLutThreads);
     if (endbit) {
         hipLaunchKernelGGL((k_rewrite_marked<true, false>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
                            left_edge, right_edge, run_in);

@@ -19,6 +19,12 @@ constexpr uint32_t kEndBit = 0x8000u;  // chunked corpora only
 
 constexpr int kTile = 512;             // slots per tile = one wave x 8 slots (one 16-byte load per lane)
 constexpr int kMergeThreads = 256;     // 4 waves per workgroup, each wave walks its own tiles
+// the kernels that hold the batch lookup table in LDS: one table per workgroup, so a large table
+// wants a large workgroup (4 waves per SIMD either way)
+#ifndef MBPE_LUT_THREADS
+#define MBPE_LUT_THREADS 512
+#endif
+constexpr int kLutThreads = MBPE_LUT_THREADS;
 constexpr int kSlotsPerLane = 8;
 
 // What a tile exposes to its neighbours.  A merge pass reads these (never the
@@ -122,11 +128,14 @@ struct DevCtl {
 // A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
 // stream (see k_select_batch).  Per batch scratch, device memory:
 #ifndef MBPE_BATCH_MAX
-#define MBPE_BATCH_MAX 256
+#define MBPE_BATCH_MAX 512
 #endif
 constexpr int kBatchMax = MBPE_BATCH_MAX;
 // candidates gathered by k_sel_scan
-constexpr uint32_t kSelCap = 2048;
+#ifndef MBPE_SEL_CAP
+#define MBPE_SEL_CAP 4096
+#endif
+constexpr uint32_t kSelCap = MBPE_SEL_CAP;
 struct SelList {
     unsigned long long packed[kSelCap];
     uint32_t eidx[kSelCap];
@@ -223,7 +232,7 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 // prefix), then k_select_batch (walks the argmax bounds one pair at a time) if that could not be used
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus, int n_ranks, uint32_t endbit);
+                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap);
 // (three gather + pick attempts are enqueued: when the first gather overflows its list -- many equal
 //  counts -- the second lists the block bounds to find a threshold and the third gathers with it)
 // small batch: count the deltas and mark the tiles (the rewrite follows validation)

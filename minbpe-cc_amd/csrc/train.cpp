@@ -183,6 +183,7 @@ struct mbpe_ctx {
     int64_t opt_multi_merge = 1;    // 1: several independent merges per stream pass (batch sequences)
     int64_t opt_max_batch = kBatchMax;
     int64_t opt_fused_min = 24;     // batches of at least this many pairs take the fused pass
+    int64_t opt_sel_cap = kSelCap;      // candidate-list capacity (tests lower it to force the overflow path)
     int64_t opt_threshold_select = 1;   // 0: always select with the bound-walking kernel
     int64_t opt_dense_table = -1;   // -1 auto / 1: dense pair table when vocab <= 32,768; 0: always hashed
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
@@ -405,6 +406,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "fused_min") c->opt_fused_min = std::max<int64_t>(2, value);
     else if (n == "dense_table") c->opt_dense_table = value;
     else if (n == "threshold_select") c->opt_threshold_select = value != 0;
+    else if (n == "sel_cap") c->opt_sel_cap = std::min<int64_t>(std::max<int64_t>(64, value), kSelCap);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
 }
@@ -674,7 +676,7 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
     launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best,
                         c->n_target, (uint32_t)c->opt_max_batch, (uint32_t)c->opt_fused_min, c->n_cus,
-                        std::max(1, c->n_ranks), endbit);
+                        std::max(1, c->n_ranks), endbit, (uint32_t)c->opt_sel_cap);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     // (the live token buffer is ctl->cur: a fused pass flips it without the host knowing)
     launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
