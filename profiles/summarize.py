@@ -3,6 +3,7 @@
 small per-kernel summaries committed under profiles/.
 
 usage: summarize.py stats <kernel_stats.csv> | trace <kernel_trace.csv> | pmc <counter_collection.csv>
+                    | sq <counter_collection.csv>   (any other counters: raw per-dispatch averages)
 PMC note (guide: /opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE and
 WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced read, so the corrected read traffic is 2 x FETCH_SIZE x 1024.
@@ -40,6 +41,16 @@ def main():
             w = [x for x in v if x >= 20.0]
             print("%s,%d,%.3f,%d,%.3f,%.2f,%.2f" % (k, len(v), sum(v) / 1e3, len(w), sum(w) / 1e3,
                                                   sum(w) / max(len(w), 1), max(v)))
+    elif mode == "sq":
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            if k:
+                agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        print("kernel,counter,dispatches,working,avg,min,max")
+        for (k, c), v in sorted(agg.items()):
+            w = [x for x in v if x >= 0.01 * max(v)] if max(v) > 0 else v
+            print("%s,%s,%d,%d,%.0f,%.0f,%.0f" % (k, c, len(v), len(w), sum(w) / len(w), min(w), max(w)))
     else:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(path)):
