@@ -2188,6 +2188,9 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, uint32_t tt
 
 // (7 waves per SIMD: the cold instantiation meets it with two spilled registers, which is cheaper than
 //  running with 6 waves; 8 would spill ten and is slower.  The delta cache of the HOT one allows 5.)
+#ifndef MBPE_SKIP_PENALTY0
+#define MBPE_SKIP_PENALTY0 2
+#endif
 #ifndef MBPE_FUSED_WAVES
 #define MBPE_FUSED_WAVES 4
 #endif
@@ -2740,7 +2743,7 @@ __global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag, const BatchState
     // passing over dependent candidates: back off after a failure, recover after successes
     if (ctl->skip_off) ctl->skip_off -= 1;
     if (ctl->batch_n >= 2 && ctl->skip_failed) {
-        const uint32_t pen = ctl->skip_penalty ? (ctl->skip_penalty * 2u > 256u ? 256u : ctl->skip_penalty * 2u) : 8u;
+        const uint32_t pen = ctl->skip_penalty ? (ctl->skip_penalty * 2u > 256u ? 256u : ctl->skip_penalty * 2u) : (uint32_t)MBPE_SKIP_PENALTY0;
         ctl->skip_penalty = pen;
         ctl->skip_off = pen;
     } else if (ctl->batch_n >= 2 && bs_skip_n > 0 && ctl->skip_penalty) {

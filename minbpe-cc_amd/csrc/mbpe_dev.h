@@ -141,7 +141,10 @@ struct SelList {
     uint32_t eidx[kSelCap];
 };
 
-constexpr int kSkipMax = 32;
+#ifndef MBPE_SKIP_MAX
+#define MBPE_SKIP_MAX 32
+#endif
+constexpr int kSkipMax = MBPE_SKIP_MAX;
 constexpr uint32_t kNoTT = 0xFFFFFFFFu;
 struct BatchState {
     uint32_t key[kBatchMax];      // (first << 16) | second
