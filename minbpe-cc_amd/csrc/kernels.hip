@@ -565,22 +565,34 @@ constexpr int kRunThreads = 256;
 constexpr int kRunPerThread = 16;
 constexpr uint32_t kRunChunk = kRunThreads * kRunPerThread;      // 4096 tiles, as tile_scan_scratch assumes
 
-struct RunSeg { unsigned long long len; bool full; };
+// (token-agnostic: the run is of whatever token the previous tile ends with, so one scan serves every
+//  (t,t) member of a batch; a consumer uses it only if its own token equals that neighbour)
+struct RunSeg { unsigned long long len; uint32_t token; bool full, empty; };
+__device__ __forceinline__ RunSeg run_none() { RunSeg o; o.len = 0; o.token = 0; o.full = true; o.empty = true; return o; }
 __device__ __forceinline__ RunSeg run_join(RunSeg l, RunSeg r) {
-    RunSeg o;
-    o.len = r.full ? l.len + r.len : r.len;
-    o.full = r.full && l.full;
+    if (r.empty) return l;
+    if (l.empty) return r;
+    RunSeg o = r;
+    if (r.full && l.token == r.token) { o.len = l.len + r.len; o.full = l.full; }
+    else o.full = false;
     return o;
 }
-__device__ __forceinline__ RunSeg run_seg_of(const TileSum &s, uint32_t t) {
+__device__ __forceinline__ RunSeg run_seg_of(const TileSum &s) {
     RunSeg o;
-    if (s.n_live == 0) { o.len = 0; o.full = true; }
-    else if (s.tail0 != t) { o.len = 0; o.full = false; }
-    else { o.len = s.tail_run; o.full = s.tail_run == s.n_live; }
+    if (s.n_live == 0) return run_none();
+    o.empty = false;
+    o.token = s.tail0;                      // raw: a token that ends its chunk equals nothing after it
+    o.len = s.tail_run;
+    o.full = s.tail_run == s.n_live;
     return o;
 }
-__device__ __forceinline__ unsigned long long run_pack(RunSeg r) { return (r.len << 1) | (r.full ? 1ull : 0ull); }
-__device__ __forceinline__ RunSeg run_unpack(unsigned long long v) { RunSeg r; r.len = v >> 1; r.full = v & 1ull; return r; }
+__device__ __forceinline__ unsigned long long run_pack(RunSeg r) {
+    return ((unsigned long long)r.token << 48) | (r.len << 2) | (r.full ? 2ull : 0ull) | (r.empty ? 1ull : 0ull);
+}
+__device__ __forceinline__ RunSeg run_unpack(unsigned long long v) {
+    RunSeg r; r.token = (uint32_t)(v >> 48); r.len = (v >> 2) & ((1ull << 46) - 1ull); r.full = (v & 2ull) != 0; r.empty = (v & 1ull) != 0;
+    return r;
+}
 
 // the token of the (t,t) pair about to be merged (alone, or as a member of a batch), or 0xFFFFFFFF when
 // this sequence merges no such pair
@@ -599,11 +611,11 @@ __device__ __forceinline__ uint32_t run_token(const unsigned long long *best_ptr
 
 // The segments of a chunk's 4096 tiles, loaded coalesced into LDS; then every thread joins its
 // kRunPerThread consecutive tiles (result also left in sh[thread]).
-__device__ __forceinline__ RunSeg run_chunk_join(const TileSum *sin, uint32_t n_tiles, uint32_t t, uint64_t base,
+__device__ __forceinline__ RunSeg run_chunk_join(const TileSum *sin, uint32_t n_tiles, uint64_t base,
                                                  unsigned long long *segs, unsigned long long *sh) {
-    RunSeg none; none.len = 0; none.full = true;
+    const RunSeg none = run_none();
     for (uint32_t i = threadIdx.x; i < kRunChunk; i += kRunThreads)
-        segs[i] = run_pack(base + i < n_tiles ? run_seg_of(sin[base + i], t) : none);
+        segs[i] = run_pack(base + i < n_tiles ? run_seg_of(sin[base + i]) : none);
     __syncthreads();
     RunSeg mine = none;
     for (int i = 0; i < kRunPerThread; ++i) mine = run_join(mine, run_unpack(segs[threadIdx.x * kRunPerThread + i]));
@@ -620,9 +632,9 @@ __global__ __launch_bounds__(kRunThreads) void k_run_partial(const TileSum *__re
     __shared__ unsigned long long sh[kRunThreads];
     const uint32_t t = run_token(best_ptr, ctl, seq, bs);
     if (t == 0xFFFFFFFFu) return;
-    run_chunk_join(sin, n_tiles, t, (uint64_t)blockIdx.x * kRunChunk, segs, sh);
+    run_chunk_join(sin, n_tiles, (uint64_t)blockIdx.x * kRunChunk, segs, sh);
     if (threadIdx.x == 0) {
-        RunSeg acc; acc.len = 0; acc.full = true;
+        RunSeg acc = run_none();
         for (int i = 0; i < kRunThreads; ++i) acc = run_join(acc, run_unpack(sh[i]));
         part[blockIdx.x] = run_pack(acc);
     }
@@ -640,13 +652,13 @@ __global__ __launch_bounds__(kRunThreads) void k_run_final(const TileSum *__rest
     if (t == 0xFFFFFFFFu) return;
     // everything before this chunk: each thread joins a slice of the chunk aggregates, thread 0 the slices
     const uint32_t nb = blockIdx.x, per = (nb + kRunThreads - 1) / kRunThreads;
-    RunSeg acc; acc.len = 0; acc.full = true;
+    RunSeg acc = run_none();
     for (uint32_t i = threadIdx.x * per; i < nb && i < (threadIdx.x + 1) * per; ++i) acc = run_join(acc, run_unpack(part[i]));
     pre[threadIdx.x] = run_pack(acc);
     const uint64_t base = (uint64_t)blockIdx.x * kRunChunk;
-    run_chunk_join(sin, n_tiles, t, base, segs, sh);            // (syncs)
+    run_chunk_join(sin, n_tiles, base, segs, sh);            // (syncs)
     if (threadIdx.x == 0) {
-        RunSeg run; run.len = 0; run.full = true;
+        RunSeg run = run_none();
         for (int i = 0; i < kRunThreads; ++i) run = run_join(run, run_unpack(pre[i]));
         for (int i = 0; i < kRunThreads; ++i) {            // exclusive scan over the threads of this chunk
             const RunSeg mine = run_unpack(sh[i]);
@@ -656,12 +668,14 @@ __global__ __launch_bounds__(kRunThreads) void k_run_final(const TileSum *__rest
     }
     __syncthreads();
     RunSeg run = run_unpack(sh[threadIdx.x]);
-    const unsigned long long edge =
-        le && le->tail0 == t ? ((unsigned long long)le->tail_run_hi << 32) | le->tail_run_lo : 0ull;
+    const unsigned long long edge = le ? ((unsigned long long)le->tail_run_hi << 32) | le->tail_run_lo : 0ull;
+    const uint32_t edge_tok = le ? le->tail0 : kHole;
     // (the per-tile results go back through LDS so that the stores are coalesced too)
     for (int i = 0; i < kRunPerThread; ++i) {
         const uint32_t k = threadIdx.x * kRunPerThread + i;
-        const unsigned long long rb = run.len + (run.full ? edge : 0ull);
+        // the left rank's trailing run continues into this shard while everything before the tile is that token
+        const bool reach = le && edge_tok != kHole && (run.empty || (run.full && run.token == edge_tok));
+        const unsigned long long rb = run.len + (reach ? edge : 0ull);
         const RunSeg here = run_unpack(segs[k]);
         segs[k] = (rb & 1ull) | (rb >= 2 ? 2ull : 0ull);
         run = run_join(run, here);
@@ -986,7 +1000,8 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
         uint32_t ea = __shfl_up(sa, 1, kWave), et = __shfl_up(st, 1, kWave);
         if (lane == 0) { ea = 1; et = 0; }
         // lanes with ea set: the run reaches back to the start of the tile
-        const uint32_t rb_small = run_in[tile];      // run of a before this tile: parity and ">= 2" (k_run_final)
+        // run of the previous tile's last token before this tile (k_run_final): parity and ">= 2"; ours if that is `a`
+        const uint32_t rb_small = h.p1 == a ? run_in[tile] : 0u;
         run = ea ? et + rb_small : et;   // parity and ">= 2" are all that is used below
     }
 
@@ -1279,6 +1294,41 @@ __device__ __forceinline__ uint32_t pair_hash(uint32_t first, uint32_t second) {
     return (__umul24(second, 2531u) + first) & (kBuckets - 1u);      // one v_mad_u32_u24
 }
 
+// The (t,t) members of the batch, for the kernel instantiations that handle them: token -> stand-in id
+// (direct-mapped on the token's low bits; k_sel_pick keeps the slots distinct), stand-in -> token and
+// batch index, and the workgroup's match counts (a (t,t) pair's matches are not its count).
+struct TTInfo {
+    uint32_t map[kTTSlots];      // token | stand-in << 16, or 0xFFFFFFFF
+    uint32_t tok[kTTMax];
+    uint32_t pair[kTTMax];
+    uint32_t cnt[kTTMax];
+};
+
+__device__ __forceinline__ void tt_build(TTInfo &ti, const BatchState *bs, uint32_t n_keys, uint32_t fake) {
+    for (uint32_t i = threadIdx.x; i < kTTSlots; i += blockDim.x) ti.map[i] = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kTTMax; i += blockDim.x) { ti.tok[i] = kHole; ti.pair[i] = 0; ti.cnt[i] = 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n = 0;
+        for (uint32_t j = 0; j < n_keys && n < (uint32_t)kTTMax; ++j) {
+            const uint32_t key = bs->key[j];
+            const uint32_t a = key >> 16;
+            if ((key & 0xFFFFu) != a) continue;
+            ti.map[a & (kTTSlots - 1u)] = a | ((fake - n) << 16);
+            ti.tok[n] = a;
+            ti.pair[n] = j;
+            ++n;
+        }
+    }
+    __syncthreads();
+}
+
+// the workgroup's match counts of the (t,t) members, added to hdr_m at the end of the kernel
+__device__ __forceinline__ void tt_flush(TTInfo &ti, uint32_t *hdr_m) {
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)kTTMax && ti.cnt[threadIdx.x]) atomicAdd(&hdr_m[ti.pair[threadIdx.x]], ti.cnt[threadIdx.x]);
+}
+
 __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys, uint32_t fake) {
     uint32_t *words = reinterpret_cast<uint32_t *>(lut.bucket);
     for (uint32_t i = threadIdx.x; i < kBuckets * kBucketKeys; i += blockDim.x) words[i] = kEmptyPair;
@@ -1286,10 +1336,12 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
     for (uint32_t i = threadIdx.x; i < kBuckets * kBucketKeys / 2; i += blockDim.x) iw[i] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
+        uint32_t n_tt = 0;
         for (uint32_t j = 0; j < n_keys; ++j) {
             const uint32_t key = bs->key[j];
             const uint32_t a = key >> 16;
-            const uint32_t b = (key & 0xFFFFu) == a ? fake : key & 0xFFFFu;     // (t,t): see tt_rename
+            uint32_t b = key & 0xFFFFu;
+            if (b == a) b = fake - n_tt++;                                       // (t,t): see tt_rename
             const uint32_t h = pair_hash(a, b);
             const uint32_t kk = a | (b << 16);
             uint32_t r = 0;                       // first free key of the bucket (selection keeps it within kBucketKeys)
@@ -1493,6 +1545,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
             bs->maxp[accepted] = 0;
             bs->skip_n = 0;                 // (this kernel ends the batch at a dependent pair
             bs->tt_index = kNoTT;           //  and merges a (t,t) pair alone)
+            bs->tt_n = 0;
             best[k0 + accepted] = cand;
         }
         ++accepted;
@@ -1599,7 +1652,8 @@ constexpr int kPickThreads = 1024;
 __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchState *bs, const SelList *sel,
                                                            unsigned long long *best, uint32_t n_target,
                                                            uint32_t max_batch, uint32_t fused_min,
-                                                           uint32_t n_ranks, int attempt, uint32_t fake_id, uint32_t sel_cap) {
+                                                           uint32_t n_ranks, int attempt, uint32_t fake_id, uint32_t sel_cap,
+                                                           uint32_t tt_max) {
     __shared__ unsigned long long sp[kSelCap];
     __shared__ uint32_t si[kSelCap];
     const uint32_t tid = threadIdx.x;
@@ -1693,15 +1747,17 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         //  earlier pair's -- and a failed pass-over costs a stream pass; after a failure dependent
         //  pairs end the batch again for a while, see k_seq_finish)
         const bool skip_allowed = ctl->skip_off == 0;
-        bool have_tt = false;
+        uint32_t n_tt = 0;                          // (t,t) members so far, and the map slots they occupy
+        unsigned long long tt_slots[kTTSlots / 64] = {};
         if (tid == 0) bs->tt_index = kNoTT;
         for (; accepted < limit && ci < n_l; ++ci) {
             const unsigned long long cand = sp[ci];
             const uint32_t count = (uint32_t)(cand >> 32), key = ~(uint32_t)cand;
             const uint32_t a = key >> 16, b = key & 0xFFFFu;
             const bool tt = a == b && count != 0;      // (t,t): a member like any other once renamed (tt_rename),
-            const bool single = count == 0 || (tt && have_tt);        // but only one per batch
-            const uint32_t h = pair_hash(a, tt ? fake_id : b);
+            const uint32_t slot = a & (kTTSlots - 1u);                //  while stand-in ids and map slots last
+            const bool single = count == 0 || (tt && (n_tt >= tt_max || ((tt_slots[slot >> 6] >> (slot & 63u)) & 1ull)));
+            const uint32_t h = pair_hash(a, tt ? fake_id - n_tt : b);
             if (accepted > 0) {
                 bool c1 = false;
                 uint32_t same_l = 0;
@@ -1712,7 +1768,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 }
                 const unsigned long long conf = __ballot(c1);
                 const uint32_t same = wave_sum(same_l);
-                if (single || (tt && conf != 0ull)) { cut = 3u; break; }
+                if (single) { cut = 3u; break; }
                 if (conf != 0ull && n_skip < (uint32_t)kSkipMax && skip_allowed) {
                     // Depends on an earlier member (shares a token with it the wrong way round): the
                     // earlier merge eats some of its occurrences, so its count will have dropped by the
@@ -1738,14 +1794,14 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 bs->packed[accepted] = cand;
                 bs->maxp[accepted] = 0;
                 best[k0 + accepted] = cand;
-                if (tt) { bs->tt_index = accepted; bs->tt_token = a; }
+                if (tt && n_tt == 0) { bs->tt_index = accepted; bs->tt_token = a; }
             }
-            have_tt |= tt;
+            if (tt) { tt_slots[slot >> 6] |= 1ull << (slot & 63u); ++n_tt; }
             ++accepted;
             if (single) { cut = 3u; ++ci; break; }
         }
         // (candidates passed over behind the last member do not matter: nothing was chosen after them)
-        if (tid == 0) { bs->skip_n = n_skip; ctl->n_skipped += n_skip; }
+        if (tid == 0) { bs->skip_n = n_skip; bs->tt_n = n_tt; ctl->n_skipped += n_skip; }
         if (tid == 0) {
             ctl->batch_n = accepted;
             ctl->commit_n = accepted;
@@ -1777,63 +1833,88 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
 }
 
 
-// A (t,t) member of a batch.  Its matches are every second token of a run of t, counted from the
-// run's start, that has a successor in the run.  Renaming, in registers only, the tokens at the odd
-// positions of every run to an id that no token has (idmask - 1) turns the pair into an ordinary
-// one, (t, fake): no two of its occurrences overlap, every renamed token is the second token of a
-// match and disappears, and all the batch machinery applies unchanged.  The position of a token in
-// its run needs the length of the run before the lane (a segmented scan over the lanes) and before the
-// tile (run_in, from k_run_final); the neighbour tokens taken from the summaries are renamed alike.
-// A t that ends its chunk can be the second token of a match but ends the run.
+// (t,t) members of a batch.  The matches of such a pair are every second token of a run of t, counted
+// from the run's start, that has a successor in the run.  Renaming, in registers only, the tokens at
+// the odd positions of every run of a member's token to an id that no token has (idmask - 1 - i for
+// the i-th member) turns the pair into an ordinary one, (t, stand-in): no two of its occurrences
+// overlap, every renamed token is the second token of a match and disappears, and all the batch
+// machinery applies unchanged.  The position of a token in its run does not depend on which token it
+// is -- it is the number of tokens equal to it immediately before it -- so ONE segmented scan over the
+// lanes serves every member: per lane (last token, length of the run it ends, "the whole lane is that
+// run"), joined from lane to lane, started from the run that ends the previous tile (run_in, from
+// k_run_final).  The neighbour tokens taken from the summaries are renamed alike.  A token that ends
+// its chunk can be the second token of a match but continues no run.
 template <bool CHUNKED>
-__device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, uint32_t t, uint32_t rb_small) {
+__device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &ti, uint32_t rb_small) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
-    constexpr uint32_t fake = idmask - 1u;
     const uint32_t lane = lane_id();
-    bool has = false, all_t = true;
-    uint32_t trail = 0;
+    auto stand_in = [&](uint32_t v) -> uint32_t {      // v: a live token at an odd position of its run
+        const uint32_t id = v & idmask;
+        const uint32_t e = ti.map[id & (kTTSlots - 1u)];
+        return (e & 0xFFFFu) == id ? (e >> 16) | (v & endbit) : v;
+    };
+    // 1. the lane's own structure.  v continues the run that `last` ends iff (v & idmask) == last
+    //    (a `last` with the chunk-end bit equals no id)
+    uint32_t last = kHole, len = 0;
+    bool full = true;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (s[j] != kHole) {
-            has |= (s[j] & idmask) == t;
-            if (s[j] == t) ++trail; else { trail = 0; all_t = false; }
+            if ((s[j] & idmask) == last) ++len;
+            else { full = full && last == kHole; len = 1; }
+            last = s[j];
         }
     }
-    uint32_t r = 0;                    // raw t's at the end of the tile (parity)
-    if (__ballot(has) != 0ull) {
-        // inclusive scan of (all_t, trail): R after L -> R.all ? (L.all, L.trail + R.trail) : R
-        uint32_t sa = all_t ? 1u : 0u, st = trail;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const uint32_t oa = __shfl_up(sa, d, kWave), ot = __shfl_up(st, d, kWave);
-            if (lane >= (uint32_t)d && sa) { st += ot; sa = oa; }
+    // 2. what ends just before the tile, folded into lane 0; only the parity of a length is ever used
+    const bool p1_runs = h.p1 != kHole && !(h.p1 & endbit);
+    const uint32_t in_last = h.p1, in_len = p1_runs ? (rb_small & 1u) : 1u;
+    auto join = [&](uint32_t o_last, uint32_t o_len, bool o_full) {       // o before (last, len, full)
+        if (last == kHole) { last = o_last; len = o_len; full = o_full; }
+        else if (o_last != kHole) {
+            if (full && (last & idmask) == o_last) { len += o_len; full = o_full; }
+            else full = false;
         }
-        uint32_t ea = __shfl_up(sa, 1, kWave), et = __shfl_up(st, 1, kWave);
-        if (lane == 0) { ea = 1; et = 0; }
-        uint32_t run = ea ? et + rb_small : et;          // only its parity is used
+    };
+    if (lane == 0) join(in_last, in_len, false);
+    // 3. inclusive scan over the lanes
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (s[j] != kHole) {
-                const bool raw_t = s[j] == t;
-                if ((s[j] & idmask) == t && (run & 1u)) s[j] = fake | (s[j] & endbit);
-                run = raw_t ? run + 1u : 0u;
-            }
-        }
-        r = rlane(run, kWave - 1);
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t ol = __shfl_up(last, d, kWave), on = __shfl_up(len | (full ? 0x80000000u : 0u), d, kWave);
+        if (lane >= (uint32_t)d) join(ol, on & 0x7FFFFFFFu, (on >> 31) != 0u);
     }
-    // the two tokens after the tile continue the count ...
+    // 4. every slot: position parity from the state before it
+    uint32_t lv = wave_from_prev(last, in_last), ln = wave_from_prev(len, in_len);
+    uint32_t odd = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (s[j] != kHole) {
+            const bool cont = (s[j] & idmask) == lv;
+            odd |= (cont && (ln & 1u)) ? 1u << j : 0u;
+            ln = cont ? ln + 1u : 1u;
+            lv = s[j];
+        }
+    }
+    if (__ballot(odd != 0u) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if ((odd >> j) & 1u) s[j] = stand_in(s[j]);
+    }
+    // 5. the two tokens after the tile continue the count ...
+    uint32_t rl = rlane(lv, kWave - 1), rn = rlane(ln, kWave - 1);
     if (h.n1 != kHole) {
-        const bool raw_t = h.n1 == t;
-        if ((h.n1 & idmask) == t && (r & 1u)) h.n1 = fake | (h.n1 & endbit);
-        r = raw_t ? r + 1u : 0u;
-        if (h.n2 != kHole && (h.n2 & idmask) == t && (r & 1u)) h.n2 = fake | (h.n2 & endbit);
+        const uint32_t n1 = h.n1;
+        const bool c1 = (n1 & idmask) == rl;
+        if (c1 && (rn & 1u)) h.n1 = stand_in(n1);
+        rn = c1 ? rn + 1u : 1u;
+        rl = n1;
+        if (h.n2 != kHole && (h.n2 & idmask) == rl && (rn & 1u)) h.n2 = stand_in(h.n2);
     }
     // ... and the two before it end a run of rb tokens: p1 is number rb - 1, p2 number rb - 2
-    if (h.p1 == t) {
-        const bool p2_t = h.p2 == t;
-        if (!(rb_small & 1u)) h.p1 = fake;
-        if (p2_t && (rb_small & 1u)) h.p2 = fake;
+    if (p1_runs) {
+        const uint32_t p1 = h.p1, p2 = h.p2;
+        if (!(rb_small & 1u)) h.p1 = stand_in(p1);
+        if (p2 == p1 && (rb_small & 1u)) h.p2 = stand_in(p2);
     }
 }
 
@@ -1898,8 +1979,7 @@ __device__ __forceinline__ Neigh tile_neighbours(const uint32_t s[8], const Halo
 template <bool CHUNKED, int DIAG = 0>
 __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, const uint32_t s[8], const Halo h,
                                                const BatchLut &lut, uint32_t n_keys, uint32_t *hdr_adj,
-                                               uint32_t *LR, DeltaCache &dc, bool dc_on, uint32_t tt_idx,
-                                               uint32_t &lane_tt) {
+                                               uint32_t *LR, DeltaCache &dc, bool dc_on, bool tt_on, TTInfo &ti) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     const Neigh nb = tile_neighbours(s, h);
@@ -1932,7 +2012,8 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
             is_a = true;
             any = true;
             const int ja = lut_index(lut, self, n1 & idmask);
-            lane_tt += (uint32_t)ja == tt_idx ? 1u : 0u;     // matches of the (t,t) member (kNoTT: none)
+            if (tt_on && (n1 & idmask) >= idmask - (uint32_t)kTTMax)      // a match of a (t,t) member: count it
+                atomicAdd(&ti.cnt[idmask - 1u - (n1 & idmask)], 1u);
             if (p1 != kHole && !(p1 & endbit)) {
                 if (p2 != kHole && pair_test(lut, p2, p1)) {               // two matches touch
                     const int jp = lut_index(lut, p2, p1);
@@ -1966,13 +2047,13 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2 || ctl->fused) return;
     if ((bs->tt_index != kNoTT) != TT) return;      // (see k_fused_batch)
-    const uint32_t tt_idx = TT ? bs->tt_index : kNoTT, tt_tok = TT ? bs->tt_token : kHole;
-    uint32_t lane_tt = 0;
+    __shared__ TTInfo ti;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
     lut_build(lut, bs, n_keys, idmask - 1u);
+    if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     if (tile < n_tiles) {
 
@@ -2004,7 +2085,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             } else {
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
-            if (TT) tt_rename<CHUNKED>(s, h, tt_tok, run_in[tile]);
+            if (TT) tt_rename<CHUNKED>(s, h, ti, run_in[tile]);
             // first live token of the lanes after this one (exact), then the candidate
             // test: some slot and its next live token form one of the batch pairs
             uint32_t lf = kHole;
@@ -2026,7 +2107,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             bool work = __ballot(cand) != 0ull || pair_test(lut, h.p1, tile_first & idmask);
             if (DIAG == 2) { asm volatile("" :: "v"((uint32_t)cand)); work = false; }
-            if (work) scan_tile_full<CHUNKED, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, dc, dc_on, tt_idx, lane_tt);
+            if (work) scan_tile_full<CHUNKED, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, dc, dc_on, TT, ti);
         }
         if (!v1) break;
         tile += n_waves;
@@ -2036,8 +2117,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     }
     if (dc_on) dc_flush(dc, LR);
     if (TT) {
-        const uint32_t m = wave_sum(lane_tt);
-        if (lane == 0 && m) atomicAdd(&hdr_m[tt_idx], m);
+        tt_flush(ti, hdr_m);
     }
 }
 
@@ -2060,8 +2140,8 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
 // match is.
 
 template <bool CHUNKED, int DIAG = 0>
-__device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, uint32_t tt_tok, uint32_t tt_idx,
-                                                 uint32_t &lane_tt, const uint32_t s[8], const uint32_t cj[8],
+__device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on, TTInfo &ti,
+                                                 const uint32_t s[8], const uint32_t cj[8],
                                                  uint32_t Am, unsigned long long m_live, uint32_t c_init, const Halo h,
                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
@@ -2135,7 +2215,8 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, uint32_t tt
             uint32_t ja = pj;
             if (is_a) {
                 ja = (uint32_t)lut_index(lut, self, cj[j] & idmask);
-                lane_tt += ja == tt_idx ? 1u : 0u;          // matches of the (t,t) member (kNoTT: none)
+                if (tt_on && (cj[j] & idmask) >= idmask - (uint32_t)kTTMax)      // a match of a (t,t) member: count it
+                    atomicAdd(&ti.cnt[idmask - 1u - (cj[j] & idmask)], 1u);
             }
             // first token of a match: (p1, a) -> (p1, X); second token: (b, n1) -> (X, n1)
             const uint32_t nb = is_a ? p1 : cj[j];                       // the neighbour the match loses
@@ -2156,10 +2237,11 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, uint32_t tt
         out[j] = nv;
     }
 
-    if (tt_tok != kHole) {              // (every renamed token was the second token of a match; be safe)
+    if (tt_on) {                        // (every renamed token was the second token of a match; be safe)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (out[j] != kHole && (out[j] & idmask) == idmask - 1u) out[j] = tt_tok | (out[j] & endbit);
+            if (out[j] != kHole && (out[j] & idmask) >= idmask - (uint32_t)kTTMax)
+                out[j] = ti.tok[idmask - 1u - (out[j] & idmask)] | (out[j] & endbit);
     }
     const uint32_t removed = rfl(wave_sum(__popc(Bm)));
     wave_rm += removed;
@@ -2212,8 +2294,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     if (n_keys < 2 || !ctl->fused) return;
     // (the instantiation with the (t,t) code only runs for batches that have such a member, like HOT)
     if ((bs->tt_index != kNoTT) != TT) return;
-    const uint32_t tt_idx = TT ? bs->tt_index : kNoTT, tt_tok = TT ? bs->tt_token : kHole;
-    uint32_t lane_tt = 0;
+    __shared__ TTInfo ti;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     uint16_t *dst = ctl->cur ? tok0 : tok1;
     const uint32_t X0 = 256u + ctl->k_done;
@@ -2221,6 +2302,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
     lut_build(lut, bs, n_keys, idmask - 1u);
+    if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     uint32_t wave_rm = 0;        // uniform
     if (tile < n_tiles) {
@@ -2252,7 +2334,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             } else {
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
-            if (TT) tt_rename<CHUNKED>(s, h, tt_tok, run_in[tile]);
+            if (TT) tt_rename<CHUNKED>(s, h, ti, run_in[tile]);
             uint32_t lf = kHole;
 #pragma unroll
             for (int j = 7; j >= 0; --j) lf = s[j] != kHole ? s[j] : lf;
@@ -2278,7 +2360,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             const bool any = Am != 0u;
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
-                outq = fused_tile_full<CHUNKED, DIAG>(t0.q, tt_tok, tt_idx, lane_tt, s, cj, Am, m_live, c_init, h, tile_first,
+                outq = fused_tile_full<CHUNKED, DIAG>(t0.q, TT, ti, s, cj, Am, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
                                                 wave_rm);
             }
@@ -2297,8 +2379,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     if (dc_on) dc_flush(dc, LR);
     if (lane == 0 && wave_rm) atomicAdd(&ctl->rm, wave_rm);
     if (TT) {                           // matches of the (t,t) member: its count is not simply the pair's count
-        const uint32_t m = wave_sum(lane_tt);
-        if (lane == 0 && m) atomicAdd(&hdr_m[tt_idx], m);
+        tt_flush(ti, hdr_m);
     }
 }
 
@@ -2470,11 +2551,12 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
             }
         }
     }
-    if (gid < commit || gid == bs->tt_index) {
+    const bool is_tt = gid < n && (bs->key[gid] >> 16) == (bs->key[gid] & 0xFFFFu);
+    if (gid < commit || is_tt) {
         // every occurrence of an (a,b), a != b, pair is merged: its count drops to 0; a (t,t) member
         // loses its matches, counted by the stream pass (overlapping occurrences: m < count)
         uint32_t m = (uint32_t)(bs->packed[gid] >> 32);
-        if (gid == bs->tt_index) { m = hdr_m[gid]; hdr_m[gid] = 0; }
+        if (is_tt) { m = hdr_m[gid]; hdr_m[gid] = 0; }
         if (m && gid < commit) table_add(t, ctl, bs->key[gid], -(int32_t)m, false);
     }
 }
@@ -2595,11 +2677,12 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
             }
         }
     }
-    if (gid < commit || gid == bs->tt_index) {
+    const bool is_tt = gid < n && (bs->key[gid] >> 16) == (bs->key[gid] & 0xFFFFu);
+    if (gid < commit || is_tt) {
         // every occurrence of an (a,b), a != b, pair is merged: its count drops to 0; a (t,t) member
         // loses its matches, counted by the stream pass (overlapping occurrences: m < count)
         uint32_t m = (uint32_t)(bs->packed[gid] >> 32);
-        if (gid == bs->tt_index) { m = hdr_m[gid]; hdr_m[gid] = 0; }
+        if (is_tt) { m = hdr_m[gid]; hdr_m[gid] = 0; }
         if (m && gid < commit) table_add(t, ctl, bs->key[gid], -(int32_t)m, false);
     }
 }
@@ -2640,10 +2723,11 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
     uint16_t *tok = ctl->cur ? tok1 : tok0;
     const uint32_t n_keys = ctl->commit_n;
     if ((bs->tt_index < n_keys) != TT) return;      // (t,t) member inside the kept prefix: see k_fused_batch
-    const uint32_t tt_tok = TT ? bs->tt_token : kHole;
+    __shared__ TTInfo ti;
     const uint32_t X0 = 256u + ctl->k_done;
     const uint32_t n_list = ctl->n_marked;
     lut_build(lut, bs, n_keys, idmask - 1u);
+    if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kLutThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
@@ -2675,7 +2759,7 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
         } else {
             h = halo_slow(sin, n_tiles, tile, le, re);
         }
-        if (TT) tt_rename<CHUNKED>(s, h, tt_tok, run_in[tile]);
+        if (TT) tt_rename<CHUNKED>(s, h, ti, run_in[tile]);
         const Neigh nb = tile_neighbours(s, h);
         bool changed = false, a1 = false, first = true;
         uint32_t p1 = nb.p1_in, my_rm = 0;
@@ -2701,7 +2785,8 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
         if (TT) {                           // (every renamed token was the second token of a match; be safe)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (s[j] != kHole && (s[j] & idmask) == idmask - 1u) s[j] = tt_tok | (s[j] & endbit);
+                if (s[j] != kHole && (s[j] & idmask) >= idmask - (uint32_t)kTTMax)
+                    s[j] = ti.tok[idmask - 1u - (s[j] & idmask)] | (s[j] & endbit);
         }
         if (changed) reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
         wave_rm += my_rm;
@@ -3113,6 +3198,8 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
                          int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap) {
     const uint32_t fake_id = (endbit ? 0x7FFFu : 0xFFFFu) - 1u;      // see tt_rename
+    // stand-in ids of (t,t) members are the kTTMax ids below the hole / end-bit mask: only while no token has them
+    const uint32_t tt_max = 256u + n_target <= fake_id + 1u - (uint32_t)kTTMax ? (uint32_t)kTTMax : 1u;
     if (sel_cap < 64u) sel_cap = 64u;
     if (sel_cap > kSelCap) sel_cap = kSelCap;
     if (sel) {
@@ -3120,7 +3207,7 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
         for (int attempt = 0; attempt < 3; ++attempt) {
             hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target, sel_cap, attempt);
             hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
-                               fused_min, (uint32_t)n_ranks, attempt, fake_id, sel_cap);
+                               fused_min, (uint32_t)n_ranks, attempt, fake_id, sel_cap, tt_max);
         }
     }
     hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch,

@@ -141,6 +141,13 @@ struct SelList {
     uint32_t eidx[kSelCap];
 };
 
+// (t,t) members of a batch: each needs an id no token has (idmask - 1 - i) and a slot of its own in the
+// kernels' token -> id map
+#ifndef MBPE_TT_MAX
+#define MBPE_TT_MAX 16
+#endif
+constexpr int kTTMax = MBPE_TT_MAX;
+constexpr uint32_t kTTSlots = 256;
 #ifndef MBPE_SKIP_MAX
 #define MBPE_SKIP_MAX 32
 #endif
@@ -153,10 +160,11 @@ struct BatchState {
     unsigned long long maxp[kBatchMax];     // largest packed (count, ~key) of the pairs merge j creates (k_delta_max)
     uint32_t adj_in[kBatchMax];   // sum_p ADJ[p][j]: matches of j directly after another match of the batch
     uint32_t adj_out[kBatchMax];  // sum_q ADJ[j][q]
-    // a (t,t) member (at most one per batch): its index, or kNoTT; its matches are every second token of a
-    // run of t, see tt_rename in kernels.hip
+    // (t,t) members (at most kTTMax per batch, in batch order): index and token of the first one (kNoTT: none) and
+    // their number; their matches are every second token of a run of t, see tt_rename in kernels.hip
     uint32_t tt_index;
     uint32_t tt_token;
+    uint32_t tt_n;
     // candidates passed over because they depend on an earlier member of the batch (see k_sel_pick)
     uint32_t skip_n;
     uint32_t skip_key[kSkipMax];
