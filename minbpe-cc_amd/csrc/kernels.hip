@@ -1856,12 +1856,13 @@ __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &
     };
     // 1. the lane's own structure.  v continues the run that `last` ends iff (v & idmask) == last
     //    (a `last` with the chunk-end bit equals no id)
-    uint32_t last = kHole, len = 0;
-    bool full = true;
+    uint32_t last = kHole, len = 0, first_id = kHole;
+    bool full = true, repeats = false;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (s[j] != kHole) {
-            if ((s[j] & idmask) == last) ++len;
+            if (last == kHole) first_id = s[j] & idmask;
+            if ((s[j] & idmask) == last) { ++len; repeats = true; }
             else { full = full && last == kHole; len = 1; }
             last = s[j];
         }
@@ -1869,6 +1870,14 @@ __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &
     // 2. what ends just before the tile, folded into lane 0; only the parity of a length is ever used
     const bool p1_runs = h.p1 != kHole && !(h.p1 & endbit);
     const uint32_t in_last = h.p1, in_len = p1_runs ? (rb_small & 1u) : 1u;
+    // (nearly every tile once the tokens are many: no live token equals the one before it, and every lane
+    //  holds one, so no token sits at an odd position and the tile ends on a run of one)
+    uint32_t rl, rn;
+    const bool cross = first_id == wave_from_prev(last, in_last);
+    if (__ballot(last == kHole) == 0ull && __ballot(repeats || cross) == 0ull) {
+        rl = rlane(last, kWave - 1);
+        rn = 1u;
+    } else {
     auto join = [&](uint32_t o_last, uint32_t o_len, bool o_full) {       // o before (last, len, full)
         if (last == kHole) { last = o_last; len = o_len; full = o_full; }
         else if (o_last != kHole) {
@@ -1900,8 +1909,10 @@ __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &
         for (int j = 0; j < 8; ++j)
             if ((odd >> j) & 1u) s[j] = stand_in(s[j]);
     }
+    rl = rlane(lv, kWave - 1);
+    rn = rlane(ln, kWave - 1);
+    }
     // 5. the two tokens after the tile continue the count ...
-    uint32_t rl = rlane(lv, kWave - 1), rn = rlane(ln, kWave - 1);
     if (h.n1 != kHole) {
         const uint32_t n1 = h.n1;
         const bool c1 = (n1 & idmask) == rl;
