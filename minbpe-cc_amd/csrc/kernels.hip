@@ -1747,6 +1747,10 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         //  earlier pair's -- and a failed pass-over costs a stream pass; after a failure dependent
         //  pairs end the batch again for a while, see k_seq_finish)
         const bool skip_allowed = ctl->skip_off == 0;
+        // a passed-over candidate is expected to lose at least this fraction of its count; a member that
+        // would still rank behind it ends the batch before the pass instead of failing validation after it
+        const unsigned long long red_q16 = (3ull * ctl->skip_red_q16) / 4ull;
+        unsigned long long skip_floor = 0;
         uint32_t n_tt = 0;                          // (t,t) members so far, and the map slots they occupy
         unsigned long long tt_slots[kTTSlots / 64] = {};
         if (tid == 0) bs->tt_index = kNoTT;
@@ -1781,9 +1785,13 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                         bs->skip_packed[n_skip] = cand;
                     }
                     ++n_skip;
+                    const unsigned long long keep = (unsigned long long)count - (((unsigned long long)count * red_q16) >> 16);
+                    const unsigned long long fl = (keep << 32) | (uint32_t)cand;
+                    skip_floor = fl > skip_floor ? fl : skip_floor;
                     continue;
                 }
                 if (conf != 0ull || same >= kBucketKeys) { cut = conf ? 1u : 2u; break; }
+                if (cand < skip_floor) { cut = 1u; break; }
             }
 #pragma unroll
             for (int r = 0; r < kPer; ++r)
@@ -2446,10 +2454,11 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
                                                           uint32_t *hdr_adj, uint32_t *LR) {
     static_assert(kBatchMax <= 1024, "one workgroup validates a batch, a thread per pair");
     __shared__ unsigned long long s_run[kValThreads];
-    __shared__ uint32_t s_commit;
+    __shared__ uint32_t s_commit, s_minfrac;
     const uint32_t tid = threadIdx.x;
     const uint32_t n = ctl->batch_n;
     if (n < 2) return;
+    if (tid == 0) s_minfrac = 0xFFFFFFFFu;
     const uint32_t X0 = 256u + ctl->k_done;
     s_run[tid] = tid < n ? bs->maxp[tid] : 0ull;
     if (tid == 0) s_commit = n;
@@ -2485,6 +2494,8 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
             if (c == bi) red += LR[lr_idx(d, i, 1)];
         }
         const unsigned long long cnt0 = bs->skip_packed[tid] >> 32;
+        const unsigned long long frac = cnt0 ? (red << 16) / cnt0 : 0ull;
+        atomicMin(&s_minfrac, (uint32_t)(frac > 65535ull ? 65535ull : frac));
         const unsigned long long later = pack_best((int32_t)(cnt0 > red ? cnt0 - red : 0ull), key);
         for (uint32_t m = pos; m < n; ++m)
             if (bs->packed[m] < later) {
@@ -2516,6 +2527,8 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
         atomicMax(&t.smax[e >> (2 * kBlockShift)], bs->packed[tid]);
     }
     if (tid == 0) {
+        // (k_sel_pick ends a batch where a passed-over candidate, less this fraction, would still beat the next member)
+        if (s_minfrac != 0xFFFFFFFFu) ctl->skip_red_q16 = (3u * ctl->skip_red_q16 + s_minfrac) / 4u;
         ctl->commit_n = commit;
         ctl->n_validation_drops += n - commit;
         if (ctl->fused && commit < n) ctl->rm = 0;      // k_rewrite_marked recounts for the prefix

@@ -121,6 +121,7 @@ struct DevCtl {
     uint32_t skip_off;          // batches during which dependent candidates end the batch again (after a failed pass-over)
     uint32_t skip_penalty;      // length of the next such period (doubles on failure, halves on success)
     uint32_t skip_failed;       // set by k_validate for k_seq_finish
+    uint32_t skip_red_q16;      // what passed-over candidates lost lately, as a fraction of their count (low estimate)
     unsigned long long n_sel_blocks;   // blocks read by the gathers (statistics)
 
 };
