@@ -1893,12 +1893,16 @@ __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &
             else full = false;
         }
     };
-    if (lane == 0) join(in_last, in_len, false);
-    // 3. inclusive scan over the lanes
+    // 3. inclusive scan over the lanes -- only needed when some lane has to pass a run on that began before
+    //    it: an empty lane, or one that is a single run continuing the previous lane's (otherwise the state
+    //    before a lane is just the previous lane's own last token and trailing run)
+    if (__ballot(last == kHole || (full && cross)) != 0ull) {
+        if (lane == 0) join(in_last, in_len, false);
 #pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint32_t ol = __shfl_up(last, d, kWave), on = __shfl_up(len | (full ? 0x80000000u : 0u), d, kWave);
-        if (lane >= (uint32_t)d) join(ol, on & 0x7FFFFFFFu, (on >> 31) != 0u);
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t ol = __shfl_up(last, d, kWave), on = __shfl_up(len | (full ? 0x80000000u : 0u), d, kWave);
+            if (lane >= (uint32_t)d) join(ol, on & 0x7FFFFFFFu, (on >> 31) != 0u);
+        }
     }
     // 4. every slot: position parity from the state before it
     uint32_t lv = wave_from_prev(last, in_last), ln = wave_from_prev(len, in_len);
