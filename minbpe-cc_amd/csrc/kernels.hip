@@ -2468,10 +2468,15 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
     if (tid == 0) s_commit = n;
     __syncthreads();
     // pairs that only exist through touching matches
-    for (uint32_t i = tid; i < n * (uint32_t)kBatchMax; i += blockDim.x) {
-        const uint32_t p = i / kBatchMax, q = i % kBatchMax;
+    // (n columns of the n rows that can hold something: n rounded up to a power of two keeps the index split cheap)
+    uint32_t nsh = 1;
+    while ((1u << nsh) < n) ++nsh;
+    for (uint32_t i2 = tid; i2 < (n << nsh); i2 += blockDim.x) {
+        const uint32_t p = i2 >> nsh, q = i2 & ((1u << nsh) - 1u);
+        if (q >= n) continue;
+        const uint32_t i = p * kBatchMax + q;
         const uint32_t w = hdr_adj[i];
-        if (!w || q >= n) continue;
+        if (!w) continue;
         const uint32_t bp = bs->key[p] & 0xFFFFu, aq = bs->key[q] >> 16;
         atomicMax(&s_run[p > q ? p : q], pack_best((int32_t)w, ((X0 + p) << 16) | (X0 + q)));   // (X_p, X_q)
         atomicMax(&s_run[q], pack_best((int32_t)bs->adj_in[q], (bp << 16) | (X0 + q)));          // (b_p, X_q), p not merged
@@ -2512,9 +2517,10 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
     __syncthreads();
     const uint32_t commit = s_commit;
     // a match of a kept pair that touches a match of a dropped pair keeps its plain neighbour
-    for (uint32_t i = tid; i < (uint32_t)(kBatchMax * kBatchMax); i += blockDim.x) {
-        const uint32_t r = i / kBatchMax, q = i % kBatchMax;
-        if (r >= n || q >= n) continue;
+    for (uint32_t i2 = tid; i2 < (n << nsh); i2 += blockDim.x) {
+        const uint32_t r = i2 >> nsh, q = i2 & ((1u << nsh) - 1u);
+        if (q >= n) continue;
+        const uint32_t i = r * kBatchMax + q;
         const uint32_t w = hdr_adj[i];
         if (!w) continue;
         if (r >= commit && q < commit) {            // dropped match r directly before kept match q
