@@ -124,6 +124,11 @@ def test_runs_and_touching_matches_across_the_cut():
     _check(b"q" + b"a" * 1001 + b"r" + b"a" * 700, [400, 1100], 256 + 14)
     _check(b"a" * 1024, [512], 256 + 12)
     _check(b"a" * 1025, [1, 1024], 256 + 12)
+    # runs of several tokens, longer than a tile, cut inside: several (t,t) members per batch, and the run
+    # that ends the left shard continues into the right one
+    data = b"a" * 3000 + b"b" * 2501 + b"ab" * 100 + b"c" * 1600 + b"b" * 777 + b"a" * 1300
+    _check(data, [1000, 4100], 256 + 24)
+    _check(data, [2999, 3001, 5501], 256 + 24)
 
 
 def test_empty_and_tiny_shards():

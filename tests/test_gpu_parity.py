@@ -409,6 +409,34 @@ def test_one_giant_run(tr):
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
+@pytest.mark.parametrize("fused_min", [2, 1000])
+def test_several_long_runs_in_one_batch(tr, fused_min):
+    """Runs of five different bytes, many of them longer than a tile and of every parity, between
+    stretches of small-alphabet noise: the pairs (a,a) .. (e,e) are candidates together, so batches
+    hold several (t,t) members (each with its own stand-in id, one run scan for all of them), and
+    their merged tokens form runs again.  Merges, counts, final stream and pair table."""
+    _defaults(tr)
+    rng = np.random.default_rng(11)
+    parts = []
+    for _ in range(160):
+        parts.append(np.full(int(rng.integers(1, 2400)), 97 + int(rng.integers(0, 5)), dtype=np.uint8))
+        parts.append(rng.integers(97, 103, size=int(rng.integers(0, 40)), dtype=np.uint8))
+    data = np.concatenate(parts)
+    vocab = 256 + 120
+    want_m, want_c = O.train(data, vocab)
+    tr.set_option("fused_min", fused_min)
+    m, c, st = tr.train_lexical(data, vocab)
+    tr.set_option("fused_min", DEFAULTS["fused_min"])
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+    ost = O.State(data)
+    for i, (a, b) in enumerate(want_m):
+        ost.merge(int(a), int(b), 256 + i)
+    assert np.array_equal(tr.stream()[0], ost.stream()[0])
+    assert {k: v for k, v in tr.pairs_dict().items() if v} == {k: v for k, v in ost.table_dict().items() if v}
+    ost.close()
+    assert st["n_batches"] < len(m)               # (t,t) pairs did share passes
+
+
 def test_large_corpus_properties(tr):
     """256 MiB of SplitMix64 bytes, 600 merges (tens of stream passes, compaction, table growth):
     size-independent properties instead of an oracle run --
