@@ -1267,6 +1267,9 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 // bucket within its two keys: a candidate that would be the third key of a
 // bucket ends the batch.  0xFFFE is never a token id (MBPE_MAX_VOCAB_*), so
 // kEmptyPair can never be asked for.
+#ifndef MBPE_PRED_NUM
+#define MBPE_PRED_NUM 4      /* quarters of the measured per-dependency loss that the prediction counts on */
+#endif
 #ifndef MBPE_LUT_KEYS
 #define MBPE_LUT_KEYS 2
 #endif
@@ -1749,7 +1752,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         const bool skip_allowed = ctl->skip_off == 0;
         // a passed-over candidate is expected to lose at least this fraction of its count; a member that
         // would still rank behind it ends the batch before the pass instead of failing validation after it
-        const unsigned long long red_q16 = (3ull * ctl->skip_red_q16) / 4ull;
+        const unsigned long long red_q16 = ((unsigned long long)MBPE_PRED_NUM * ctl->skip_red_q16) / 4ull;
         unsigned long long skip_floor = 0;
         uint32_t n_tt = 0;                          // (t,t) members so far, and the map slots they occupy
         unsigned long long tt_slots[kTTSlots / 64] = {};
@@ -1764,10 +1767,12 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             const uint32_t h = pair_hash(a, tt ? fake_id - n_tt : b);
             if (accepted > 0) {
                 bool c1 = false;
-                uint32_t same_l = 0;
+                uint32_t same_l = 0, conf_l = 0;
 #pragma unroll
                 for (int r = 0; r < kPer; ++r) {      // (unused slots hold 0xFFFFFFFF: never equal)
-                    c1 |= b == my_a[r] || a == my_b[r];
+                    const uint32_t k1 = (b == my_a[r] ? 1u : 0u) + (a == my_b[r] ? 1u : 0u);
+                    conf_l += k1;
+                    c1 |= k1 != 0u;
                     same_l += my_h[r] == h ? 1u : 0u;
                 }
                 const unsigned long long conf = __ballot(c1);
@@ -1785,7 +1790,10 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                         bs->skip_packed[n_skip] = cand;
                     }
                     ++n_skip;
-                    const unsigned long long keep = (unsigned long long)count - (((unsigned long long)count * red_q16) >> 16);
+                    // (it loses occurrences to every member it depends on: red_q16 is the fraction per such member)
+                    unsigned long long lose = (unsigned long long)wave_sum(conf_l) * red_q16;
+                    if (lose > 65536ull) lose = 65536ull;
+                    const unsigned long long keep = (unsigned long long)count - (((unsigned long long)count * lose) >> 16);
                     const unsigned long long fl = (keep << 32) | (uint32_t)cand;
                     skip_floor = fl > skip_floor ? fl : skip_floor;
                     continue;
@@ -2497,13 +2505,14 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
         const uint32_t pos = bs->skip_pos[tid], key = bs->skip_key[tid];
         const uint32_t c = key >> 16, d = key & 0xFFFFu;
         unsigned long long red = 0;
+        uint32_t n_dep = 0;
         for (uint32_t i = 0; i < pos && i < n; ++i) {
             const uint32_t ai = bs->key[i] >> 16, bi = bs->key[i] & 0xFFFFu;
-            if (d == ai) red += LR[lr_idx(c, i, 0)];
-            if (c == bi) red += LR[lr_idx(d, i, 1)];
+            if (d == ai) { red += LR[lr_idx(c, i, 0)]; ++n_dep; }
+            if (c == bi) { red += LR[lr_idx(d, i, 1)]; ++n_dep; }
         }
         const unsigned long long cnt0 = bs->skip_packed[tid] >> 32;
-        const unsigned long long frac = cnt0 ? (red << 16) / cnt0 : 0ull;
+        const unsigned long long frac = cnt0 && n_dep ? ((red << 16) / cnt0) / n_dep : 0ull;
         atomicMin(&s_minfrac, (uint32_t)(frac > 65535ull ? 65535ull : frac));
         const unsigned long long later = pack_best((int32_t)(cnt0 > red ? cnt0 - red : 0ull), key);
         for (uint32_t m = pos; m < n; ++m)
