@@ -240,6 +240,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("k_fused_batch", args.bytes, args.vocab, world),
                 "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 PMC passes of this workload)",
+                "limiter": "vector instruction issue, not HBM: ~350 VALU wave-instructions per 512-slot tile keep the "
+                           "SIMDs ~90 % busy (profiles/r01_final_pmc_sq.csv, DESIGN.md section 4)",
                 "algorithmic_bytes_per_launch": pass_bytes,
                 "avg_launch_ms": avg_fused_ms,
                 "launches": n_fused,

@@ -88,7 +88,7 @@ typedef struct {
     uint32_t n_sel_retry;      /* batches whose first candidate gather overflowed (threshold found among the block bounds) */
     uint32_t adapt_limit;      /* current batch size limit learnt from validation */
     uint64_t n_sel_blocks;     /* 1024-entry blocks of the pair table read by the candidate gathers */
-    uint32_t size_hist[8];     /* passes by merges committed: 1, 2-3, 4-7, 8-15, 16-31, 32-63, 64-127, 128 */
+    uint32_t size_hist[8];     /* passes by merges committed: 1, 2-3, 4-7, 8-15, 16-31, 32-63, 64-127, 128 and more */
     uint32_t n_skipped;        /* dependent candidates passed over by the selection (merged in a later pass) */
     uint32_t n_skip_cut;       /* ... that had not fallen behind the batch after all (the batch was cut there) */
 } mbpe_stats;
