@@ -1872,7 +1872,9 @@ __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &
     };
     // 1. the lane's own structure.  v continues the run that `last` ends iff (v & idmask) == last
     //    (a `last` with the chunk-end bit equals no id)
-    uint32_t last = kHole, len = 0, first_id = kHole;
+    //    Also, per slot: is its position odd counted from the lane's start (lodd), and does it belong to
+    //    the lane's leading run (lead) -- only those slots' positions depend on what came before the lane.
+    uint32_t last = kHole, len = 0, first_id = kHole, lodd = 0, lead = 0;
     bool full = true, repeats = false;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1880,6 +1882,8 @@ __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &
             if (last == kHole) first_id = s[j] & idmask;
             if ((s[j] & idmask) == last) { ++len; repeats = true; }
             else { full = full && last == kHole; len = 1; }
+            lodd |= (len & 1u) ? 0u : 1u << j;
+            lead |= full ? 1u << j : 0u;
             last = s[j];
         }
     }
@@ -1912,25 +1916,19 @@ __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &
             if (lane >= (uint32_t)d) join(ol, on & 0x7FFFFFFFu, (on >> 31) != 0u);
         }
     }
-    // 4. every slot: position parity from the state before it
-    uint32_t lv = wave_from_prev(last, in_last), ln = wave_from_prev(len, in_len);
-    uint32_t odd = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (s[j] != kHole) {
-            const bool cont = (s[j] & idmask) == lv;
-            odd |= (cont && (ln & 1u)) ? 1u << j : 0u;
-            ln = cont ? ln + 1u : 1u;
-            lv = s[j];
-        }
-    }
+    // 4. every slot's position parity: the leading run's positions shift by the length of the run that the
+    //    lane's first token continues
+    const uint32_t lv = wave_from_prev(last, in_last), ln = wave_from_prev(len, in_len);
+    const uint32_t odd = lodd ^ ((first_id == lv && (ln & 1u)) ? lead : 0u);
     if (__ballot(odd != 0u) != 0ull) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             if ((odd >> j) & 1u) s[j] = stand_in(s[j]);
     }
-    rl = rlane(lv, kWave - 1);
-    rn = rlane(ln, kWave - 1);
+    // (after the scan a lane's (last, len) is the state at its end; without it no lane continued its neighbour's
+    //  run as a whole, so the lane's own values are that state already)
+    rl = rlane(last, kWave - 1);
+    rn = rlane(len, kWave - 1);
     }
     // 5. the two tokens after the tile continue the count ...
     if (h.n1 != kHole) {
