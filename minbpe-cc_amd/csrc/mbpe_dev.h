@@ -132,6 +132,8 @@ struct DevCtl {
 #define MBPE_BATCH_MAX 512
 #endif
 constexpr int kBatchMax = MBPE_BATCH_MAX;
+static_assert((kBatchMax & (kBatchMax - 1)) == 0 && kBatchMax >= 64,
+              "a power of two: grid strides over the delta arrays keep a thread on one pair index");
 // candidates gathered by k_sel_scan
 #ifndef MBPE_SEL_CAP
 #define MBPE_SEL_CAP 4096
