@@ -2425,14 +2425,16 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
 // the batch is the reference's next choice iff its packed (count, ~key) -- ties resolved by key,
 // exactly like the argmax -- beats every pair the merges before it can have created.
 
-__global__ void k_adj_sums(const uint32_t *__restrict__ hdr_adj, BatchState *bs, const DevCtl *ctl) {
-    const uint32_t n = ctl->batch_n, j = threadIdx.x;
-    if (n < 2 || j >= (uint32_t)kBatchMax) return;
+// (one wave per pair j: column j and row j of the n x n block)
+__global__ __launch_bounds__(kWave) void k_adj_sums(const uint32_t *__restrict__ hdr_adj, BatchState *bs, const DevCtl *ctl) {
+    const uint32_t n = ctl->batch_n, j = blockIdx.x;
+    if (n < 2) return;
     uint32_t in = 0, out = 0;
     if (j < n)
-        for (uint32_t p = 0; p < n; ++p) { in += hdr_adj[p * kBatchMax + j]; out += hdr_adj[j * kBatchMax + p]; }
-    bs->adj_in[j] = in;
-    bs->adj_out[j] = out;
+        for (uint32_t p = threadIdx.x; p < n; p += kWave) { in += hdr_adj[p * kBatchMax + j]; out += hdr_adj[j * kBatchMax + p]; }
+    in = wave_sum(in);
+    out = wave_sum(out);
+    if (threadIdx.x == 0) { bs->adj_in[j] = in; bs->adj_out[j] = out; }
 }
 
 // per pair j: the largest packed value among the pairs (x, X_j), (X_j, y) it creates
@@ -3357,7 +3359,7 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     uint32_t blocks = (uint32_t)((cells + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 2) blocks = 2;
-    hipLaunchKernelGGL(k_adj_sums, dim3(1), dim3(kBatchMax), 0, s, hdr_adj, bs, ctl);
+    hipLaunchKernelGGL(k_adj_sums, dim3(kBatchMax), dim3(kWave), 0, s, hdr_adj, bs, ctl);
     hipLaunchKernelGGL(k_delta_max, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, LR, bs, ctl);
     hipLaunchKernelGGL(k_validate, dim3(1), dim3(kValThreads), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     if (t.cells) {
