@@ -2507,27 +2507,42 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
     // candidates the selection passed over because an earlier member eats some of their occurrences:
     // (c, a_i) loses L_i[c], (b_i, d) loses R_i[d].  With those measured, the candidate must rank below
     // every member chosen after it; the batch ends at the first member it still beats.
-    if (tid < bs->skip_n) {
-        const uint32_t pos = bs->skip_pos[tid], key = bs->skip_key[tid];
-        const uint32_t c = key >> 16, d = key & 0xFFFFu;
-        unsigned long long red = 0;
-        uint32_t n_dep = 0;
-        for (uint32_t i = 0; i < pos && i < n; ++i) {
-            const uint32_t ai = bs->key[i] >> 16, bi = bs->key[i] & 0xFFFFu;
-            if (d == ai) { red += LR[lr_idx(c, i, 0)]; ++n_dep; }
-            if (c == bi) { red += LR[lr_idx(d, i, 1)]; ++n_dep; }
-        }
-        const unsigned long long cnt0 = bs->skip_packed[tid] >> 32;
-        const unsigned long long frac = cnt0 && n_dep ? ((red << 16) / cnt0) / n_dep : 0ull;
-        atomicMin(&s_minfrac, (uint32_t)(frac > 65535ull ? 65535ull : frac));
-        const unsigned long long later = pack_best((int32_t)(cnt0 > red ? cnt0 - red : 0ull), key);
-        for (uint32_t m = pos; m < n; ++m)
-            if (bs->packed[m] < later) {
-                atomicMin(&s_commit, m);
-                atomicAdd(&ctl->n_skip_cut, 1u);
-                ctl->skip_failed = 1;
-                break;
+    // (a wave per passed-over candidate, its lanes striding over the members)
+    {
+        const uint32_t lane = tid % kWave, n_w = blockDim.x / kWave, n_skip = bs->skip_n;
+        for (uint32_t si = tid / kWave; si < n_skip; si += n_w) {
+            const uint32_t pos = bs->skip_pos[si], key = bs->skip_key[si];
+            const uint32_t c = key >> 16, d = key & 0xFFFFu;
+            unsigned long long red = 0;
+            uint32_t n_dep = 0;
+            for (uint32_t i = lane; i < pos && i < n; i += kWave) {
+                const uint32_t ai = bs->key[i] >> 16, bi = bs->key[i] & 0xFFFFu;
+                if (d == ai) { red += LR[lr_idx(c, i, 0)]; ++n_dep; }
+                if (c == bi) { red += LR[lr_idx(d, i, 1)]; ++n_dep; }
             }
+#pragma unroll
+            for (int dd = kWave / 2; dd > 0; dd >>= 1) {
+                const uint32_t lo = __shfl_xor((uint32_t)red, dd, kWave), hi = __shfl_xor((uint32_t)(red >> 32), dd, kWave);
+                red += ((unsigned long long)hi << 32) | lo;
+            }
+            n_dep = wave_sum(n_dep);
+            const unsigned long long cnt0 = bs->skip_packed[si] >> 32;
+            const unsigned long long frac = cnt0 && n_dep ? ((red << 16) / cnt0) / n_dep : 0ull;
+            const unsigned long long later = pack_best((int32_t)(cnt0 > red ? cnt0 - red : 0ull), key);
+            uint32_t first = 0xFFFFFFFFu;                       // first member behind it that it still beats
+            for (uint32_t m = pos + lane; m < n; m += kWave)
+                if (bs->packed[m] < later) { first = m; break; }
+#pragma unroll
+            for (int dd = kWave / 2; dd > 0; dd >>= 1) { const uint32_t o = __shfl_xor(first, dd, kWave); first = o < first ? o : first; }
+            if (lane == 0) {
+                atomicMin(&s_minfrac, (uint32_t)(frac > 65535ull ? 65535ull : frac));
+                if (first != 0xFFFFFFFFu) {
+                    atomicMin(&s_commit, first);
+                    atomicAdd(&ctl->n_skip_cut, 1u);
+                    ctl->skip_failed = 1;
+                }
+            }
+        }
     }
     __syncthreads();
     const uint32_t commit = s_commit;
