@@ -1580,11 +1580,6 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
 // all gathered ones.  T only decides how many candidates come back; k_sel_pick adapts it, and
 // leaves the batch to k_select_batch when the list is empty or overflowed.
 
-// block looked at by lane `l` of wave `wave` in step `step` of k_sel_scan (a bijection onto 0 .. steps * 64 * n_waves)
-__device__ __forceinline__ uint64_t sel_block(uint64_t step, uint32_t l, uint32_t n_waves, uint32_t wave) {
-    return (((step * 8u + (l >> 3)) * n_waves + wave) << 3) | (l & 7u);
-}
-
 __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelList *sel, uint32_t n_target, uint32_t sel_cap,
                                                   int attempt) {
     if (attempt > 0 && (ctl->sel_ok || !ctl->sel_retry)) return;
@@ -1597,17 +1592,16 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
     const uint32_t lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave, n_waves = gridDim.x * blockDim.x / kWave;
-    // Blocks are dealt out round robin in groups of 8 (one 64-byte sector of bounds): the blocks above
+    // Blocks are dealt out round robin (block B belongs to wave B mod n_waves): the blocks above
     // the threshold are usually neighbours (the same few first tokens), and a wave reads its blocks
-    // one after the other, so whole runs of them must not land in one wave; single blocks per wave
-    // would make every bound its own memory transaction.
+    // one after the other.  The price is that the 64 bounds a wave looks at per step are strided.
     uint32_t blocks_read = 0;
     for (uint64_t step = 0; step * n_waves * kWave < n_blocks; ++step) {
         // far more entries than the list holds: no point in reading on, k_sel_pick will look for a
         // better threshold among the block bounds
         if (!bounds_only &&
             __hip_atomic_load(&ctl->sel_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4u * sel_cap) break;
-        const uint64_t B64 = sel_block(step, lane, n_waves, wave);
+        const uint64_t B64 = (step * kWave + lane) * n_waves + wave;
         const uint32_t B = (uint32_t)B64;
         const unsigned long long bound = B64 < n_blocks
             ? __hip_atomic_load(&t.bmax[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
@@ -1626,7 +1620,7 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
             if (__hip_atomic_load(&ctl->sel_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4u * sel_cap) break;
             const uint32_t b = (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1ull;
-            const uint32_t blk = (uint32_t)sel_block(step, b, n_waves, wave);
+            const uint32_t blk = (uint32_t)((step * kWave + b) * n_waves + wave);
             unsigned long long mx = 0;
             // (all 16 loads of the block are issued before the first one is looked at)
             unsigned long long pv[kBlockSize / kWave];
