@@ -2477,18 +2477,26 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
     __syncthreads();
     // pairs that only exist through touching matches
     // (n columns of the n rows that can hold something: n rounded up to a power of two keeps the index split cheap)
-    uint32_t nsh = 1;
+    // (at least 64 columns per row, so a wave stays inside one row p: what goes to s_run[p] is reduced over the wave
+    //  first -- 64 LDS atomics on one address would serialise)
+    uint32_t nsh = 6;
     while ((1u << nsh) < n) ++nsh;
-    for (uint32_t i2 = tid; i2 < (n << nsh); i2 += blockDim.x) {
+    for (uint32_t i0 = 0; i0 < (n << nsh); i0 += blockDim.x) {
+        const uint32_t i2 = i0 + tid;
         const uint32_t p = i2 >> nsh, q = i2 & ((1u << nsh) - 1u);
-        if (q >= n) continue;
-        const uint32_t i = p * kBatchMax + q;
-        const uint32_t w = hdr_adj[i];
-        if (!w) continue;
-        const uint32_t bp = bs->key[p] & 0xFFFFu, aq = bs->key[q] >> 16;
-        atomicMax(&s_run[p > q ? p : q], pack_best((int32_t)w, ((X0 + p) << 16) | (X0 + q)));   // (X_p, X_q)
-        atomicMax(&s_run[q], pack_best((int32_t)bs->adj_in[q], (bp << 16) | (X0 + q)));          // (b_p, X_q), p not merged
-        atomicMax(&s_run[p], pack_best((int32_t)bs->adj_out[p], ((X0 + p) << 16) | aq));         // (X_p, a_q), q not merged
+        const bool in_range = p < n && q < n;
+        const uint32_t w = in_range ? hdr_adj[p * kBatchMax + q] : 0u;
+        unsigned long long to_p = 0;
+        if (w) {
+            const uint32_t bp = bs->key[p] & 0xFFFFu, aq = bs->key[q] >> 16;
+            const unsigned long long xx = pack_best((int32_t)w, ((X0 + p) << 16) | (X0 + q));            // (X_p, X_q)
+            if (q > p) atomicMax(&s_run[q], xx); else to_p = xx;
+            atomicMax(&s_run[q], pack_best((int32_t)bs->adj_in[q], (bp << 16) | (X0 + q)));              // (b_p, X_q), p not merged
+            const unsigned long long xa = pack_best((int32_t)bs->adj_out[p], ((X0 + p) << 16) | aq);     // (X_p, a_q), q not merged
+            to_p = xa > to_p ? xa : to_p;
+        }
+        to_p = wave_max_u64(to_p);
+        if (tid % kWave == 0 && to_p) atomicMax(&s_run[p], to_p);
     }
     __syncthreads();
     for (uint32_t d = 1; d < (uint32_t)kValThreads; d <<= 1) {        // inclusive prefix maximum
