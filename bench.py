@@ -3,20 +3,30 @@
 
 Contract (driver): python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by torch.distributed.run, one rank per GPU.
-A "step" is one iteration of the training loop (reference Tokenizer.h:557-589):
-one merge = argmax over the pair table + merge of that pair in the token stream
-+ count update.  (The library applies several independent merges per pass over
-the stream when it can prove the result identical; steps still count merges.)
-With the defaults the timed region is the whole training run to vocab 32,000
-minus the warm-up merges.  The workload is BASELINE.json config 4: a SplitMix64(seed 42)
-uniform-random byte corpus, `basic` encoder (one chunk), vocab 32,000.  The
-corpus is generated on the device, so it is resident in HBM before the timed
-region; the initial pair-count scan and stream setup run before the timed
-region and are reported separately (pair_count_scan_*).
+
+A "step" is one *batch sequence*, the unit the library executes (mbpe_train_sequences):
+select the next maxima that are provably independent -> ONE pass over the token stream that
+merges them all -> validate against the reference's one-at-a-time order -> apply the count
+updates.  It is the loop body of the reference (Tokenizer.h:557-589: get_top_pair_count,
+merge_chunks -> merge_incremental) for up to 512 consecutive iterations at once.  W warm-up
+sequences run untimed, then exactly K sequences are timed between barriers;
+    value = merges those K sequences committed / wall time       (merges/s, whole job)
+
+Workload (--config synthetic, the default): BASELINE.json config 4 -- SplitMix64(seed 42)
+uniform-random bytes, 4 GiB whole job, `basic` encoder (one chunk), vocab 32,000.  The corpus is
+generated on the device, so it is resident in HBM before anything is timed; the pair-count scan
+(the other half of BASELINE.json's metric) is timed on its own (pair_count_scan_*).
+--config bible: BASELINE.json config 3 with the documented stand-in corpus (data/bible.txt is absent
+from the reference checkout): shakespeare.txt x 4 = 4,461,576 bytes, vocab 10,000.
+
+After the timed region, outside it, the same process runs the WHOLE training to the target
+vocabulary (`full_run`) and checks the result on the device (`checks`): decode(stream) == corpus,
+chosen counts never increase, every rank holds the same merges.
 
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "minbpe-cc_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 GOLDEN = 0x9E3779B97F4A7C15
+PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def _s64(v):
@@ -58,62 +69,88 @@ def splitmix64_device(seed, n, device, offset_bytes=0):
     return out, b
 
 
-def pmc_traffic(kernel, corpus_bytes, vocab, world):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), for the
-    workload they were taken on; None for any other configuration."""
+def bible_standin_device(device, lo, hi):
+    """shakespeare.txt x 4, bytes [lo, hi), in a 16-byte aligned device buffer."""
+    import numpy as np
+    import torch
+    with open(os.path.join(ROOT, "tests", "golden", "data", "shakespeare.txt"), "rb") as f:
+        one = f.read()
+    data = np.frombuffer(one * 4, dtype=np.uint8)[lo:hi]
+    keep = torch.zeros((len(data) + 15) // 16 * 2, dtype=torch.int64, device=device)
+    b = keep.view(torch.uint8)[:len(data)]
+    b.copy_(torch.from_numpy(data.copy()))
+    return keep, b
+
+
+def pmc_traffic(kernel, config, corpus_bytes, vocab, world):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), for the
+    workload they were taken on; None for any other configuration or kernel."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             d = json.load(f)
         w = d["workload"]
-        if w["corpus_bytes"] == corpus_bytes and w["vocab_size"] == vocab and w["n_gpus"] == world:
+        if (w.get("config", "synthetic") == config and w["corpus_bytes"] == corpus_bytes
+                and w["vocab_size"] == vocab and w["n_gpus"] == world):
             return d[kernel]["hbm_bytes"]
     except (OSError, KeyError, ValueError):
         pass
     return None
 
 
-def cpu_baseline(seed, sample_bytes, merges, vocab):
-    """The CPU oracle (a port of the reference algorithm: sequential pass per
-    merge + incremental counts + ordered argmax) timed on one host core."""
+def cpu_baseline(data, merges, what):
+    """The CPU oracle (a port of the reference algorithm: sequential pass per merge + incremental
+    counts + ordered argmax) timed on one host core.  Checker code, used here only as the baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    data = O.splitmix64_bytes(seed, sample_bytes)
     t0 = time.perf_counter()
     st = O.State(data)
     t1 = time.perf_counter()
+    done = 0
     for i in range(merges):
         top = st.top()
+        if top is None:
+            break
         st.merge(top[0], top[1], 256 + i)
+        done += 1
+        if time.perf_counter() - t1 > 30.0:
+            break
     t2 = time.perf_counter()
     st.close()
     return {
-        "value": merges / (t2 - t1),
+        "value": done / (t2 - t1),
         "unit": "merges/s",
         "cores": 1,
         "kind": "port",
-        "sample": "first %d MiB of the workload corpus, first %d merges, single thread (the reference is "
-                  "single-threaded); per-merge cost is linear in corpus bytes" % (sample_bytes >> 20, merges),
-        "sample_bytes": sample_bytes,
-        "pair_count_scan_MBps": sample_bytes / 1e6 / (t1 - t0),
+        "sample": "%s, first %d merges, single thread (the reference is single-threaded); per-merge cost is "
+                  "linear in corpus bytes" % (what, done),
+        "sample_bytes": len(data),
+        "pair_count_scan_MBps": len(data) / 1e6 / (t1 - t0),
         "host_cores_available": os.cpu_count(),
     }
+
+
+FUSED_LIMITER = ("vector instruction issue, not HBM (SQ counters in profiles/, DESIGN.md section 4)")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=31728, help="merges timed (default: the whole training run)")
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--bytes", type=int, default=4 << 30, help="corpus bytes (whole job)")
-    ap.add_argument("--vocab", type=int, default=32000)
+    ap.add_argument("--steps", type=int, default=20, help="batch sequences timed")
+    ap.add_argument("--warmup", type=int, default=5, help="batch sequences before the timed region")
+    ap.add_argument("--config", choices=["synthetic", "bible"], default="synthetic")
+    ap.add_argument("--bytes", type=int, default=4 << 30, help="corpus bytes, whole job (synthetic)")
+    ap.add_argument("--vocab", type=int, default=0, help="default 32000 (synthetic) / 10000 (bible)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--cpu-merges", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-run", action="store_true", help="skip the untimed full training + checks")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import mbpe
+    from mbpe import check as C
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -128,12 +165,17 @@ def main():
         dist = dist_mod
         dist.init_process_group("nccl", device_id=device)
 
-    steps = min(args.steps, args.vocab - 256 - args.warmup)
-    # ---- corpus shard of this rank (contiguous byte range, 8-byte aligned cuts)
-    per = (args.bytes // world) // 4096 * 4096
+    bible = args.config == "bible"
+    vocab = args.vocab or (10000 if bible else 32000)
+    total_bytes = 4 * 1115394 if bible else args.bytes
+    # ---- corpus shard of this rank (contiguous byte range, 4096-byte aligned cuts)
+    per = (total_bytes // world) // 4096 * 4096
     lo = rank * per
-    hi = args.bytes if rank == world - 1 else lo + per
-    keep, corpus = splitmix64_device(args.seed, hi - lo, device, lo)
+    hi = total_bytes if rank == world - 1 else lo + per
+    if bible:
+        keep, corpus = bible_standin_device(device, lo, hi)
+    else:
+        keep, corpus = splitmix64_device(args.seed, hi - lo, device, lo)
     torch.cuda.synchronize()
 
     tr = mbpe.Trainer(local_rank)
@@ -146,105 +188,163 @@ def main():
         tr.comm_init(uid[0], rank, world)
     tr.load_corpus_device(corpus.data_ptr(), hi - lo, keep=keep)
 
-    # ---- pair-count scan (graded kernel): a few timed launches
-    scan_ms = []
-    for _ in range(5):
-        tr.pair_count_u8(want_table=False)
-        scan_ms.append(tr.stats()["ms_pair_count"])
-    scan_ms_best = sorted(scan_ms)[len(scan_ms) // 2]
-
-    tr.set_option("time_kernels", 1)
-    tr.train_begin(args.vocab)
-    begin_stats = tr.stats()
-    tr.train_steps(args.warmup)
-    s0 = tr.stats()
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- pair-count scan (graded kernel): a few timed launches, median
+    scan_ms = []
+    for _ in range(7):
+        tr.pair_count_u8(want_table=False)
+        scan_ms.append(tr.stats()["ms_pair_count"])
+    scan_ms_med = sorted(scan_ms)[len(scan_ms) // 2]
+
+    # ---- timed region: K sequences after W warm-up sequences
+    tr.set_option("time_kernels", 1)
+    tr.train_begin(vocab)
+    begin_stats = tr.stats()
+    warm_merges = tr.train_sequences(args.warmup) if args.warmup else 0
+    s0 = tr.stats()
     barrier()
     t0 = time.perf_counter()
-    done = tr.train_steps(steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    done = tr.train_sequences(args.steps)
+    barrier()
     t1 = time.perf_counter()
     s1 = tr.stats()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(t1 - t0)
 
-    merges, counts = tr.train_result()
-    # ---- the dominant kernel: k_fused_batch, one pass = one read of the stream + the merged stream
-    # written to the other buffer, for every pair of the batch at once.  Bytes such a pass has to move:
-    # 2 B read + 2 B written per slot.
-    n_fused = s1["fused_launches"] - s0["fused_launches"]
-    ms_fused = s1["ms_fused_kernel"] - s0["ms_fused_kernel"]
-    slots_fused = s1["fused_slots"] - s0["fused_slots"]
-    avg_fused_ms = ms_fused / max(n_fused, 1)
-    pass_bytes = 4.0 * slots_fused / max(n_fused, 1)
-    achieved = pass_bytes / (avg_fused_ms * 1e-3) / 1e9 if avg_fused_ms > 0 else 0.0
+    # ---- the dominant kernel inside the timed region.  A fused pass (k_fused_batch) reads the stream once,
+    # counts the deltas of every pair of the batch and writes the merged stream to the other buffer:
+    # 2 B read + 2 B written per slot.  Small batches take the read-only pass (k_scan_batch / k_merge).
     n_pass = s1["n_batches"] - s0["n_batches"]
-    roof_kernel = ("k_fused_batch: reads the stream once, counts the deltas of every pair of the batch and "
-                   "writes the merged stream to the other buffer")
-    if n_fused == 0:
-        # a short timed region may hold small batches only: those read the stream once (k_scan_batch /
-        # k_merge) and write where a match is; report that pass instead
-        n_fused = s1["merge_launches"] - s0["merge_launches"]
-        avg_fused_ms = (s1["ms_merge_kernel"] - s0["ms_merge_kernel"]) / max(n_fused, 1)
+    n_fused = s1["fused_launches"] - s0["fused_launches"]
+    n_other = (s1["merge_launches"] - s0["merge_launches"]) - n_fused
+    ms_fused = s1["ms_fused_kernel"] - s0["ms_fused_kernel"]
+    ms_all = s1["ms_merge_kernel"] - s0["ms_merge_kernel"]
+    if n_fused > 0 and ms_fused >= 0.5 * ms_all:
+        roof_name = "k_fused_batch"
+        roof_desc = ("reads the stream once, counts the deltas of every pair of the batch and writes the "
+                     "merged stream to the other buffer (2 B read + 2 B written per slot)")
+        launches = n_fused
+        avg_ms = ms_fused / n_fused
+        pass_bytes = 4.0 * (s1["fused_slots"] - s0["fused_slots"]) / n_fused
+        limiter = FUSED_LIMITER
+    else:
+        roof_name = "k_scan_batch"
+        roof_desc = "the read-only stream pass of small batches (k_scan_batch / k_merge; 2 B read per slot)"
+        launches = max(n_other, 1)
+        avg_ms = (ms_all - ms_fused) / launches
         pass_bytes = 2.0 * s1["n_slots"]
-        achieved = pass_bytes / (avg_fused_ms * 1e-3) / 1e9 if avg_fused_ms > 0 else 0.0
-        roof_kernel = "k_scan_batch / k_merge: the read-only stream pass of small batches (no fused pass in the timed region)"
+        limiter = None
+    achieved = pass_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # SURVEY.md 8(d) prices a merge step at 2 B x L read + 2 B x L' written; a pass performs
     # merges_per_pass of them on one read: the same sum divided by the measured time
     live_avg = 0.5 * (s0["n_live"] + s1["n_live"])
     ref_model_bytes = 4.0 * live_avg * (done / max(n_pass, 1))
-    scan_gbs = (hi - lo) / (scan_ms_best * 1e-3) / 1e9
+    scan_gbs = (hi - lo) / (scan_ms_med * 1e-3) / 1e9
+    timed = {"sequences": args.steps, "stream_passes": n_pass, "merges": done,
+             "first_merge": warm_merges, "fused_passes": n_fused,
+             "slots_begin": s0["n_slots"], "live_begin": s0["n_live"], "live_end": s1["n_live"],
+             "seconds": elapsed, "ms_stream_kernels": ms_all, "ms_fused_kernel": ms_fused}
+
+    # ---- untimed: the whole training to the target vocabulary, then checks on the device
+    full_run, checks = None, None
+    if not args.no_full_run:
+        tr.set_option("time_kernels", 0)
+        barrier()
+        f0 = time.perf_counter()
+        tr.train_begin(vocab)
+        n_done = tr.train_steps(vocab - 256)
+        barrier()
+        f1 = time.perf_counter()
+        fs = tr.stats()
+        f_el = max_over_ranks(f1 - f0)
+        merges, counts = tr.train_result()
+        full_run = {"merges": int(len(merges)), "seconds": f_el, "merges_per_s": len(merges) / f_el,
+                    "passes": fs["n_batches"], "fused_passes": fs["n_fused"], "fused_abandoned": fs["n_fused_dropped"],
+                    "begin_ms": fs["ms_begin"], "steps_ms": fs["ms_steps"], "compactions": fs["n_compactions"],
+                    "live_end": fs["n_live"], "slots_end": fs["n_slots"], "pairs": fs["n_pairs"],
+                    "includes": "pair-count scan, stream + table setup, every sequence, host housekeeping"}
+        rt = C.decode_roundtrip(tr, merges, corpus, torch, device)
+        digest = hashlib.sha256(merges.tobytes() + counts.tobytes()).hexdigest()
+        same = True
+        if dist is not None:
+            got = [None] * world
+            dist.all_gather_object(got, digest)
+            same = all(g == got[0] for g in got)
+            flag = torch.tensor([1.0 if rt["ok"] else 0.0], dtype=torch.float64, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            rt["ok_all_ranks"] = bool(flag.item() == 1.0)
+        checks = {
+            "decode_roundtrip": rt,
+            "counts_nonincreasing": C.counts_nonincreasing(counts),
+            "merges_complete": int(len(merges)) == vocab - 256,
+            "ranks_identical_merges": same,
+            "merges_sha256": digest,
+            "first_counts": [int(c) for c in counts[:3]],
+            "last_counts": [int(c) for c in counts[-3:]],
+        }
+        checks["ok"] = bool(rt["ok"] and rt.get("ok_all_ranks", True) and checks["counts_nonincreasing"]
+                            and checks["merges_complete"] and same)
 
     if rank == 0:
+        if bible:
+            workload = ("BASELINE config 3 stand-in (data/bible.txt is absent from the reference checkout): "
+                        "shakespeare.txt x 4 = %d bytes, basic encoder (one chunk), vocab %d, lexicographic "
+                        "tie-break" % (total_bytes, vocab))
+        else:
+            workload = ("BASELINE config 4: SplitMix64(seed %d) uniform-random bytes, %d bytes whole job, basic "
+                        "encoder (one chunk), vocab %d, lexicographic tie-break" % (args.seed, total_bytes, vocab))
         out = {
             "metric": "bpe_train_merges_per_sec",
             "value": done / elapsed,
             "unit": "merges/s",
             "n_gpus": world,
-            "steps": done,
+            "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / max(done, 1),
+            "ms_per_step": elapsed * 1e3 / max(args.steps, 1),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u16",
-            "data": "synthetic",
+            "data": "synthetic" if not bible else "shakespeare.txt x 4 (fixture)",
             "config": {
-                "workload": "SplitMix64(seed %d) uniform-random bytes, %d bytes whole job, basic encoder "
-                            "(one chunk), vocab %d, lexicographic tie-break; steps are merges %d..%d"
-                            % (args.seed, args.bytes, args.vocab, args.warmup, args.warmup + done),
-                "corpus_bytes": args.bytes,
-                "vocab_size": args.vocab,
-                "parallelism": "stream sharded over %d GPU(s), pair table replicated" % world,
+                "workload": workload + "; a step is one batch sequence (select -> one stream pass -> validate -> "
+                            "apply), timed steps are sequences %d..%d = merges %d..%d"
+                            % (args.warmup, args.warmup + args.steps, warm_merges, warm_merges + done),
+                "corpus_bytes": total_bytes,
+                "vocab_size": vocab,
+                "parallelism": "stream sharded over %d GPU(s), pair table replicated, one sum all-reduce of the "
+                               "count deltas per sequence" % world,
             },
+            "timed_region": timed,
+            "merges_per_step": done / max(args.steps, 1),
             "pair_count_scan_MBps": scan_gbs * 1e3 * world,
-            "pair_count_scan_ms": scan_ms_best,
+            "pair_count_scan_ms": scan_ms_med,
             "roofline": {
-                "kernel": roof_kernel,
+                "kernel": roof_name,
+                "what": roof_desc,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("k_fused_batch", args.bytes, args.vocab, world),
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 PMC passes of this workload)",
-                "limiter": "vector instruction issue, not HBM: ~350 VALU wave-instructions per 512-slot tile keep the "
-                           "SIMDs ~90 % busy (profiles/r01_final_pmc_sq.csv, DESIGN.md section 4)",
+                "traffic": pmc_traffic(roof_name, args.config, total_bytes, vocab, world),
+                "traffic_source": PMC_FILE + " (rocprofv3 PMC passes of this workload; null when none was taken "
+                                  "for this kernel / configuration)",
+                "limiter": limiter,
                 "algorithmic_bytes_per_launch": pass_bytes,
-                "avg_launch_ms": avg_fused_ms,
-                "launches": n_fused,
+                "avg_launch_ms": avg_ms,
+                "launches": launches,
                 "stream_passes": n_pass,
                 "merges_per_pass": done / max(n_pass, 1),
                 "survey_8d_model": {
@@ -262,25 +362,37 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": scan_gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("k_pair_count_u8", args.bytes, args.vocab, world),
+                "traffic": pmc_traffic("k_pair_count_u8", args.config, total_bytes, vocab, world),
                 "algorithmic_bytes_per_launch": hi - lo,
-                "avg_launch_ms": scan_ms_best,
+                "avg_launch_ms": scan_ms_med,
+                "launch_ms_all": scan_ms,
             },
             "begin_ms": begin_stats["ms_begin"],
-            "stream": {"slots": s1["n_slots"], "live": s1["n_live"], "compactions": s1["n_compactions"],
-                       "pairs": s1["n_pairs"]},
+            "full_run": full_run,
+            "checks": checks,
             "batches": {k: s1[k] for k in ("n_batches", "n_fused", "n_fused_dropped", "cut_conflict", "cut_bucket",
-                                           "cut_single", "cut_full", "n_validation_drops", "ms_grow_table", "ms_compact",
-                                           "n_table_grows", "ms_steps", "n_sel_fallback", "n_sel_retry", "size_hist", "n_skipped", "n_skip_cut")},
-            "first_counts": [int(c) for c in counts[:3]],
+                                           "cut_single", "cut_full", "n_validation_drops", "n_sel_fallback",
+                                           "n_sel_retry", "size_hist", "n_skipped", "n_skip_cut")},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.seed, min(args.cpu_sample_mib << 20, args.bytes),
-                                               args.cpu_merges, args.vocab)
+            if bible:
+                sample = corpus.cpu().numpy()
+                what = "the whole stand-in corpus (%d bytes)" % len(sample)
+            else:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle as O
+                sample = O.splitmix64_bytes(args.seed, min(args.cpu_sample_mib << 20, total_bytes))
+                what = "first %d MiB of the workload corpus" % (len(sample) >> 20)
+            out["cpu_baseline"] = cpu_baseline(sample, args.cpu_merges if not bible else vocab - 256, what)
         print(json.dumps(out))
+        if checks is not None and not checks["ok"]:
+            print("bench.py: the full run FAILED its checks: %s" % json.dumps(checks), file=sys.stderr)
+    failed = checks is not None and not checks["ok"]
     tr.close()
     if dist is not None:
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

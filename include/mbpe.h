@@ -145,6 +145,15 @@ MBPE_API int mbpe_train_begin(mbpe_ctx *ctx, uint32_t vocab_size);
  * call. */
 MBPE_API int mbpe_train_steps(mbpe_ctx *ctx, uint32_t n_steps, uint32_t *steps_done_out);
 
+/* Runs up to n_sequences *batch sequences*, the unit the library executes: select the next
+ * maxima that are provably independent (get_top_pair_count, PairCount.h:262-269, for up to
+ * "max_batch" consecutive iterations) -> one pass over the token stream that merges them all
+ * (merge_chunks, Tokenizer.h:309-320) -> validate against the one-at-a-time order -> apply the
+ * count updates (Tokenizer.h:239-280).  Every sequence commits at least one merge of the loop
+ * Tokenizer.h:557-589 unless training is complete; merges_done_out (optional) receives the
+ * number this call committed.  With "multi_merge" 0 a sequence is one merge. */
+MBPE_API int mbpe_train_sequences(mbpe_ctx *ctx, uint32_t n_sequences, uint32_t *merges_done_out);
+
 /* Copies the merges made so far: merges_out[2k], merges_out[2k+1] is the
  * pair that became token 256+k (Tokenizer.h:578); counts_out[k] (optional)
  * is its count when chosen (the verbose line, Tokenizer.h:566-576).
@@ -170,6 +179,13 @@ MBPE_API int mbpe_get_stats(mbpe_ctx *ctx, mbpe_stats *out);
  * where a token is the last of its chunk. */
 MBPE_API int mbpe_get_stream(mbpe_ctx *ctx, uint32_t *tokens_out, uint8_t *chunk_end_out,
                              uint64_t cap, uint64_t *n_out);
+
+/* Device view of the slot stream, for checks that run on the device (tests, bench.py): n_slots
+ * slots of slot_bits bits each in device memory, valid until the next training call.  A slot equal
+ * to the all-ones value is a hole; end_bit (0 for a one-chunk corpus) is the slot bit that marks the
+ * last token of a chunk, the token id is the slot without it. */
+MBPE_API int mbpe_stream_device(mbpe_ctx *ctx, const void **slots_out, uint64_t *n_slots_out,
+                                uint32_t *slot_bits_out, uint32_t *end_bit_out);
 
 /* All pairs ever inserted with their current counts
  * (PairCount::get_all, PairCount.h:271-278; order unspecified).

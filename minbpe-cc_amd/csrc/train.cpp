@@ -772,12 +772,15 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
 }
 
 // the batch-sequence loop of mbpe_train_steps (one GPU, or several over RCCL)
-static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
+// (max_seqs: stop after that many sequences, however many merges they committed)
+static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out,
+                               uint32_t max_seqs = 0xFFFFFFFFu) {
     const uint32_t start = c->k;
-    const uint32_t target = std::min<uint32_t>(c->n_target, c->k + n_steps);
+    const uint32_t target = (uint32_t)std::min<uint64_t>(c->n_target, (uint64_t)c->k + n_steps);
     HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->ctl->k_limit), (int)target, 1, c->stream));
-    while (c->k < target && !c->exhausted) {
-        const uint32_t group = seqs_per_sync(c);
+    uint32_t seqs_left = max_seqs;
+    while (c->k < target && !c->exhausted && seqs_left) {
+        const uint32_t group = std::min<uint32_t>(seqs_per_sync(c), seqs_left);
         if (!c->tab.cells && (uint64_t)c->h_ctl.n_entries + seq_headroom(c) * group > c->tab.ecap) {
             int rc = grow_table(c, ((uint64_t)c->h_ctl.n_entries + seq_headroom(c) * group) * 2);
             if (rc != MBPE_OK) return rc;
@@ -843,6 +846,7 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
         rc = after_batch(c);
         if (rc != MBPE_OK) return rc;
         if (c->k == before) break;      // nothing left to merge
+        seqs_left -= launched;
     }
     if (steps_done_out) *steps_done_out = c->k - start;
     return MBPE_OK;
@@ -921,6 +925,19 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
     }
     if (steps_done_out) *steps_done_out = done;
     return MBPE_OK;
+}
+
+int mbpe_train_sequences(mbpe_ctx *c, uint32_t n_sequences, uint32_t *merges_done_out) {
+    if (merges_done_out) *merges_done_out = 0;
+    if (!c) return MBPE_ERR_ARG;
+    if (!c->begun) { mbpe_host::set_last_error("mbpe_train_sequences before mbpe_train_begin"); return MBPE_ERR_STATE; }
+    if (c->pending || (is_multi(c) && c->comm_external)) {
+        mbpe_host::set_last_error("mbpe_train_sequences: not available with an external transport (use mbpe_train_steps)");
+        return MBPE_ERR_STATE;
+    }
+    if (!use_batches(c)) return mbpe_train_steps(c, n_sequences, merges_done_out);   // one merge per pass
+    HIPCHK(hipSetDevice(c->device));
+    return train_steps_batched(c, c->n_target, merges_done_out, n_sequences);
 }
 
 int mbpe_comm_exchange_buffer(mbpe_ctx *c, void **dev_ptr_out, uint64_t *n_u32_out) {
@@ -1078,6 +1095,20 @@ int mbpe_get_stream(mbpe_ctx *c, uint32_t *tokens_out, uint8_t *chunk_end_out, u
         ++w;
     }
     *n_out = w;
+    return MBPE_OK;
+}
+
+int mbpe_stream_device(mbpe_ctx *c, const void **slots_out, uint64_t *n_slots_out, uint32_t *slot_bits_out,
+                       uint32_t *end_bit_out) {
+    if (!c || !slots_out || !n_slots_out) return MBPE_ERR_ARG;
+    if (!c->begun) { mbpe_host::set_last_error("mbpe_stream_device before mbpe_train_begin"); return MBPE_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = sync_ctl(c);          // also refreshes which of the two buffers is live
+    if (rc != MBPE_OK) return rc;
+    *slots_out = c->tok[c->cur];
+    *n_slots_out = c->n_slots;
+    if (slot_bits_out) *slot_bits_out = 16;
+    if (end_bit_out) *end_bit_out = c->chunked ? kEndBit : 0;
     return MBPE_OK;
 }
 

@@ -21,8 +21,8 @@ COMM_ID_BYTES = 128
 # every symbol include/mbpe.h declares
 EXPORTS = [
     "mbpe_last_error", "mbpe_version", "mbpe_create", "mbpe_destroy", "mbpe_load_corpus",
-    "mbpe_pair_count_u8", "mbpe_train_begin", "mbpe_train_steps", "mbpe_train_result",
-    "mbpe_train_lexical", "mbpe_get_stats", "mbpe_get_stream", "mbpe_get_pairs", "mbpe_compact",
+    "mbpe_pair_count_u8", "mbpe_train_begin", "mbpe_train_steps", "mbpe_train_sequences", "mbpe_train_result",
+    "mbpe_train_lexical", "mbpe_get_stats", "mbpe_get_stream", "mbpe_stream_device", "mbpe_get_pairs", "mbpe_compact",
     "mbpe_set_option", "mbpe_comm_unique_id", "mbpe_comm_init", "mbpe_comm_init_external",
     "mbpe_comm_exchange_buffer", "mbpe_comm_exchange_done", "mbpe_presplit",
     "mbpe_split_count", "mbpe_split_offsets", "mbpe_split_free", "mbpe_split_pattern",
@@ -83,10 +83,12 @@ def lib():
     L.mbpe_pair_count_u8.argtypes = [vp, vp]
     L.mbpe_train_begin.argtypes = [vp, u32]
     L.mbpe_train_steps.argtypes = [vp, u32, vp]
+    L.mbpe_train_sequences.argtypes = [vp, u32, vp]
     L.mbpe_train_result.argtypes = [vp, vp, vp, u32, vp]
     L.mbpe_train_lexical.argtypes = [vp, vp, u64, vp, u64, u32, vp, vp, vp, vp]
     L.mbpe_get_stats.argtypes = [vp, vp]
     L.mbpe_get_stream.argtypes = [vp, vp, vp, u64, vp]
+    L.mbpe_stream_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.mbpe_get_pairs.argtypes = [vp, vp, vp, vp, u64, vp]
     L.mbpe_compact.argtypes = [vp]
     L.mbpe_set_option.argtypes = [vp, ctypes.c_char_p, i64]
@@ -212,6 +214,12 @@ class Trainer:
         rc = _check(lib().mbpe_train_steps(self._h, n_steps, ctypes.byref(done)))
         return rc if self._external else done.value
 
+    def train_sequences(self, n_sequences):
+        """Runs up to n_sequences batch sequences (see mbpe_train_sequences); returns the merges they committed."""
+        done = ctypes.c_uint32()
+        _check(lib().mbpe_train_sequences(self._h, n_sequences, ctypes.byref(done)))
+        return done.value
+
     _external = False
 
     def comm_init_external(self, rank, n_ranks):
@@ -264,6 +272,13 @@ class Trainer:
         ends = np.zeros(max(n.value, 1), dtype=np.uint8)
         _check(lib().mbpe_get_stream(self._h, toks.ctypes.data, ends.ctypes.data, n.value, ctypes.byref(n)))
         return toks[:n.value], ends[:n.value]
+
+    def stream_device(self):
+        """(device pointer, n_slots, slot_bits, end_bit) of the live slot stream (see mbpe_stream_device)."""
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        bits, end = ctypes.c_uint32(), ctypes.c_uint32()
+        _check(lib().mbpe_stream_device(self._h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(bits), ctypes.byref(end)))
+        return p.value, n.value, bits.value, end.value
 
     def pairs(self):
         n = ctypes.c_uint64()

@@ -1,0 +1,120 @@
+"""Size-independent checks of a training run, done on the device with torch (plumbing only: the
+product never imports this; bench.py and tests/ do).
+
+  * decode round trip: expanding the live token stream through the merges gives back the corpus,
+    byte for byte (nothing lost, duplicated or reordered by thousands of in-place stream passes),
+  * the chosen counts never increase: a pair created by a merge occurs at most as often as the pair
+    it came from, every other pair can only lose occurrences (reference loop Tokenizer.h:557-589),
+  * recount: the adjacent pairs of the final stream, counted from scratch, equal the pair table
+    that was maintained incrementally (merge_incremental, Tokenizer.h:239-280).
+"""
+import numpy as np
+
+
+def token_tables(merges, max_len=None):
+    """Byte expansion of every token: lens[v] and bytes_[v, :lens[v]] (vocab[256+k] = vocab[a] ++ vocab[b],
+    reference Tokenizer.h:562-564)."""
+    n = 256 + len(merges)
+    exp = [bytes([i]) for i in range(256)]
+    for a, b in merges:
+        exp.append(exp[int(a)] + exp[int(b)])
+    lens = np.fromiter((len(e) for e in exp), dtype=np.int64, count=n)
+    width = int(lens.max()) if max_len is None else max_len
+    tab = np.zeros((n, width), dtype=np.uint8)
+    for i, e in enumerate(exp):
+        tab[i, :len(e)] = np.frombuffer(e, dtype=np.uint8)
+    return lens, tab
+
+
+def live_tokens(tr, torch, device, lo=0, hi=None):
+    """Token ids (int32) and chunk-end flags (bool) of the live slots in [lo, hi) of the device stream."""
+    ptr, n_slots, bits, end_bit = tr.stream_device()
+    hi = n_slots if hi is None else min(hi, n_slots)
+    if bits == 16:
+        raw = _as_tensor(torch, ptr + 2 * lo, hi - lo, torch.int16, device).to(torch.int32) & 0xFFFF
+        hole = 0xFFFF
+    else:
+        raw = _as_tensor(torch, ptr + 4 * lo, hi - lo, torch.int32, device)
+        hole = -1
+    raw = raw[raw != hole]
+    if end_bit:
+        return raw & ~end_bit, (raw & end_bit) != 0
+    return raw, None
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of raw device memory (so torch can wrap it without a copy)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def _as_tensor(torch, ptr, n, dtype, device):
+    typestr = {torch.int16: "<i2", torch.int32: "<i4", torch.uint8: "|u1"}[dtype]
+    if n == 0:
+        return torch.empty(0, dtype=dtype, device=device)
+    return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
+
+
+def decode_roundtrip(tr, merges, corpus, torch, device, slots_per_piece=1 << 28):
+    """True iff decode(live stream) == corpus.  corpus: uint8 tensor on `device` (this rank's shard)."""
+    lens_h, tab_h = token_tables(merges)
+    lens_t = torch.from_numpy(lens_h).to(device)
+    tab_t = torch.from_numpy(tab_h).to(device)
+    width = tab_h.shape[1]
+    _, n_slots, _, _ = tr.stream_device()
+    base = 0
+    n_live = 0
+    ok = True
+    for lo in range(0, n_slots, slots_per_piece):
+        toks, _ = live_tokens(tr, torch, device, lo, lo + slots_per_piece)
+        if toks.numel() == 0:
+            continue
+        n_live += int(toks.numel())
+        if int(toks.max()) >= len(lens_h):
+            return {"ok": False, "why": "token id beyond the vocabulary", "n_live": n_live}
+        toks = toks.long()
+        ln = lens_t[toks]
+        ends = torch.cumsum(ln, 0)
+        starts = ends - ln + base
+        total = base + int(ends[-1])
+        if total > corpus.numel():
+            return {"ok": False, "why": "decoded stream longer than the corpus", "n_live": n_live}
+        for j in range(width):
+            if j == 0:
+                sel_t, sel_s = toks, starts
+            else:
+                m = ln > j
+                if not bool(m.any()):
+                    break
+                sel_t, sel_s = toks[m], starts[m]
+            if not bool((corpus[sel_s + j] == tab_t[sel_t, j]).all()):
+                ok = False
+                break
+        base = total
+        del toks, ln, ends, starts
+        if not ok:
+            break
+    if ok and base != corpus.numel():
+        return {"ok": False, "why": "decoded %d bytes, corpus has %d" % (base, corpus.numel()), "n_live": n_live}
+    return {"ok": ok, "why": "" if ok else "decoded bytes differ from the corpus", "n_live": n_live,
+            "decoded_bytes": base, "max_token_bytes": width}
+
+
+def counts_nonincreasing(counts):
+    c = np.asarray(counts, dtype=np.int64)
+    return bool(np.all(np.diff(c) <= 0))
+
+
+def recount_pairs(tr, torch, device):
+    """{(a, b): count} of the adjacent live pairs of the device stream, counted from scratch (pairs
+    do not start at the last token of a chunk: Tokenizer.h:135-144)."""
+    toks, ends = live_tokens(tr, torch, device)
+    if toks.numel() < 2:
+        return {}
+    key = toks[:-1].long() * (1 << 32) + toks[1:].long()
+    if ends is not None:
+        key = key[~ends[:-1]]
+    u, c = torch.unique(key, return_counts=True)
+    u, c = u.cpu().numpy(), c.cpu().numpy()
+    return {(int(k >> 32), int(k & 0xFFFFFFFF)): int(v) for k, v in zip(u, c)}

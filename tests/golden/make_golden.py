@@ -1,8 +1,17 @@
 #!/usr/bin/env python3
 """Regenerates tests/golden/*.model with the CPU oracle and checks each file
-against the sha256 recorded in SURVEY.md section 8c (digests of .model files the
-reference itself produced during the survey).  A fixture is only written
-when its digest matches, so the committed files ARE the reference's outputs.
+against the sha256 recorded in SURVEY.md section 8c.  A fixture is only written
+when its digest matches.
+
+Where the digests come from: the survey session compiled the reference's two
+headers against a stand-in for Boost.MultiIndex (the image has no Boost) and
+hashed the .model files that build wrote.  That is NOT a build of the reference
+as shipped, so on its own it pins nothing.  What ties the committed fixtures to
+the reference's algorithm is tests/test_bruteforce_cpu.py: an independent
+recount-per-merge BPE in numpy (no oracle code, chunk boundaries from Python's
+`regex`) reproduces the lexical AND first-mode fixtures byte for byte, and the
+reference-held known-answer tests (test.cpp:15-106, :136-186) are checked in
+tests/test_oracle.py.
 
 Inputs: tests/golden/data/*.txt are the reference's own data files
 (data/taylorswift.txt, shakespeare.txt, small.txt, sample.txt, special1.txt,
