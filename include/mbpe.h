@@ -170,6 +170,22 @@ MBPE_API int mbpe_train_lexical(mbpe_ctx *ctx, const uint8_t *text, uint64_t n_b
                                 uint32_t *merges_out, int32_t *counts_out,
                                 uint32_t *n_merges_out, mbpe_stats *stats_out);
 
+/* The same for either CONFLICT_RESOLUTION of Tokenizer::train (minbpe-cc.cpp:129-131):
+ * conflict_resolution 1 = LEXICAL (what mbpe_train_lexical runs), 0 = FIRST -- the reference
+ * CLI's default: among the pairs of maximal count the one inserted first into a table rebuilt
+ * before every merge wins (PairCountInsertOrder, PairCount.h:65-74, :141-152; recount
+ * Tokenizer.h:581-585), i.e. the one whose first occurrence in the corpus comes first.  The
+ * device keeps the exact counts incrementally and settles ties with one pass over the stream
+ * that finds the earliest position of a tied pair; one merge per pass, one GPU, corpus < 4 GiB.
+ * With FIRST the loop ends when no pair is left (Tokenizer.h:586-588): n_merges_out may then be
+ * smaller than vocab_size - 256.  Step-level use: mbpe_set_option("conflict_resolution", 0)
+ * before mbpe_train_begin. */
+MBPE_API int mbpe_train(mbpe_ctx *ctx, const uint8_t *text, uint64_t n_bytes,
+                        const uint64_t *chunk_off, uint64_t n_chunks, uint32_t vocab_size,
+                        int conflict_resolution,
+                        uint32_t *merges_out, int32_t *counts_out,
+                        uint32_t *n_merges_out, mbpe_stats *stats_out);
+
 MBPE_API int mbpe_get_stats(mbpe_ctx *ctx, mbpe_stats *out);
 
 /* ---- introspection (parity tests) ----------------------------------- */
@@ -186,6 +202,12 @@ MBPE_API int mbpe_get_stream(mbpe_ctx *ctx, uint32_t *tokens_out, uint8_t *chunk
  * last token of a chunk, the token id is the slot without it. */
 MBPE_API int mbpe_stream_device(mbpe_ctx *ctx, const void **slots_out, uint64_t *n_slots_out,
                                 uint32_t *slot_bits_out, uint32_t *end_bit_out);
+
+/* Device view of the dense pair table (vocab_size <= 32,768 unless "dense_table" is 0; MBPE_ERR_STATE
+ * for the hashed layout): 1 << (2 * vshift) u32 cells, cell of (a, b) at
+ *   ((((a >> 5) << (vshift - 5)) | (b >> 5)) << 10) | ((a & 31) << 5) | (b & 31),
+ * value 0x80000000 | count once the pair was ever inserted (PairCount.h:249-260 never erases), else 0. */
+MBPE_API int mbpe_table_device(mbpe_ctx *ctx, const void **cells_out, uint32_t *vshift_out);
 
 /* All pairs ever inserted with their current counts
  * (PairCount::get_all, PairCount.h:271-278; order unspecified).
@@ -214,6 +236,8 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *                   (single-merge mode)
  *   "force_exchange" 1 = take the multi-rank path (rank edges, exchange) even
  *                   with a single rank (tests the RCCL binding on one GPU)
+ *   "conflict_resolution" 1 = lexical tie-break (default), 0 = first (see mbpe_train); before
+ *                   mbpe_train_begin only
  *   "time_kernels"  1 = bracket every merge kernel with HIP events on the
  *                   context's stream; totals appear in mbpe_stats
  */

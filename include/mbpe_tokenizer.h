@@ -28,9 +28,9 @@ MBPE_API void mbpe_tok_destroy(mbpe_tokenizer *t);
 /* set_special_tokens_from_file, Tokenizer.h:476-486: "name id" pairs. */
 MBPE_API int mbpe_tok_set_special_tokens(mbpe_tokenizer *t, const char *text, uint64_t n);
 
-/* train, Tokenizer.h:489-598.  conflict_resolution: 1 = lexical (the MI355X
- * path, device `device_id`); 0 = first is the reference's slow path and is
- * not provided (MBPE_ERR_ARG). */
+/* train, Tokenizer.h:489-598.  conflict_resolution: 1 = lexical, 0 = first
+ * (the reference CLI's default); both run on HIP device `device_id` through
+ * mbpe_train. */
 MBPE_API int mbpe_tok_train(mbpe_tokenizer *t, const uint8_t *text, uint64_t n, uint32_t vocab_size,
                             int conflict_resolution, int verbose, int device_id);
 

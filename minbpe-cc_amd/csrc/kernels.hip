@@ -64,6 +64,11 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int d) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, d, kWave), hi = __shfl_xor((uint32_t)(v >> 32), d, kWave);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -249,31 +254,53 @@ __global__ void k_fill_u16(uint16_t *p, uint64_t n, uint16_t v) {
 // ---- pair-count scan ------------------------------------------------------
 // One workgroup per CU keeps a private histogram of all 65,536 byte pairs in
 // LDS as packed 16-bit counters (128 KiB of the CU's 160 KiB).  Each lane
-// reads 16 corpus bytes with one 16-byte load (the next iteration's load is
-// issued before the current one is consumed) and issues 16 fire-and-forget
-// LDS atomics: nothing in the inner loop waits for the LDS.
+// reads 16 corpus bytes per 16-byte load (the next iteration's loads are
+// issued before the current ones are consumed) and issues 16 fire-and-forget
+// LDS atomics per vector: nothing in the inner loop waits for the LDS.  The kernel
+// is bound by the LDS atomics themselves: 64 random bins per wave instruction
+// conflict about 3.5-way on the 32 banks a 32-lane group shares.
 //
 // bin = first | second << 8 (the little-endian 16-bit value at the pair's
 // offset), then bin ^= bin >> 8 so that the LDS bank (low bits) mixes both
 // bytes -- text uses few distinct first bytes; counter word = bin & 0x7FFF,
 // half = bin >> 15.
 //
-// Exactness of the 16-bit counters: an epoch is three iterations of the
-// 1024-thread workgroup = 49,152 increments.  At every epoch boundary the
-// workgroup sweeps the histogram (conflict-free 16-byte LDS reads) and moves
-// every counter >= 0x2000 to the global table.  So every counter is < 0x2000
-// when an epoch starts and gains at most 0xC000 inside it: it never wraps.
+// Exactness of the 16-bit counters, for any input.  A counter wraps after 65,536 increments,
+// and a workgroup adds 32,768 per iteration, so in the worst case (one pair repeated) the
+// histogram would have to be swept every iteration -- which is what costs a third of the
+// time on data that never needs it.  Instead the workgroup runs SEGMENTS of iterations with
+// no sweep and no barrier, and proves afterwards that nothing wrapped:
+//   * every lane counts the increments it issued; the sum over the workgroup plus the
+//     decoded sum of the counters before the segment is what the decoded sum must be now;
+//   * a counter that wrapped lowers the decoded sum by 65,535 (low half: its carry lands in
+//     the high half) or 65,536 (high half: the carry is lost), never raises it: the sums
+//     agree  <=>  no counter wrapped  <=>  every counter is exact;
+//   * if they disagree the segment is void: the histogram is restored from the snapshot taken
+//     at the segment's start (128 KiB of plain stores to the workgroup's scratch) and the
+//     segment is recounted by the slow loop, which sweeps every 49,152 increments and
+//     moves counters >= 0x2000 to the global table, so that none can wrap.
+// After a good segment counters >= 0x2000 are drained as well (the slow loop relies on it).
+// Segment length adapts: it doubles while the largest counter stays small and restarts at
+// kPcSeg0 iterations after a void segment.  Uniform data never takes the slow loop; a
+// corpus that is one repeated byte takes it for every segment.
 constexpr int kPcThreads = 1024;
 constexpr int kPcWords = 32768;            // 2 counters per word
 constexpr uint32_t kPcHotBits = 0xE000u;   // counter >= 0x2000
-constexpr int kPcEpochIters = 3;
+constexpr int kPcEpochIters = 3;           // slow loop: iterations of one vector per lane between sweeps
+constexpr int kPcVpl = 2;                  // fast loop: vectors per lane and iteration
+#ifndef MBPE_PC_SEG0
+#define MBPE_PC_SEG0 16
+#endif
+constexpr uint32_t kPcSeg0 = MBPE_PC_SEG0;  // first segment, in fast iterations of 32 Ki pairs
+constexpr uint32_t kPcSegMax = 4096;
 
 __device__ __forceinline__ uint32_t pc_table_index(uint32_t hbin) {
     const uint32_t bin = hbin ^ (hbin >> 8);         // undo the bank hash
     return ((bin & 0xFFu) << 8) | (bin >> 8);        // -> (first << 8) | second
 }
 
-// epoch sweep: thread t owns the 16-byte groups t, t+1024, ... of the histogram
+// sweep: thread t owns the 16-byte groups t, t+1024, ... of the histogram; counters >= 0x2000 move
+// to the global table
 __device__ __forceinline__ void pc_sweep(uint32_t *hist, uint32_t *bp) {
 #pragma unroll
     for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k) {
@@ -305,85 +332,189 @@ __device__ __forceinline__ void pc_flush(const uint32_t *hist, uint32_t *bp) {
     }
 }
 
-template <bool MASKED>
-__global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__restrict__ text, uint64_t n,
-                                                              const uint8_t *__restrict__ endmask,
-                                                              uint32_t *__restrict__ bp) {
-    __shared__ uint32_t hist[kPcWords];
-    for (uint32_t w = threadIdx.x; w < (uint32_t)kPcWords; w += kPcThreads) hist[w] = 0;
+// workgroup-wide: decoded sum of all counters + `issued` summed over the threads, and the largest counter
+struct PcCheck { unsigned long long sum, issued; uint32_t max; };
+__device__ __forceinline__ PcCheck pc_check(const uint32_t *hist, unsigned long long issued,
+                                            unsigned long long *red /* [3 * 16] */) {
+    unsigned long long s = 0;
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k) {
+        const uint4 v = reinterpret_cast<const uint4 *>(hist)[k * kPcThreads + threadIdx.x];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t lo = w[c] & 0xFFFFu, hi = w[c] >> 16;
+            s += lo + hi;
+            m = lo > m ? lo : m;
+            m = hi > m ? hi : m;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s += shfl_xor_u64(s, d);
+        issued += shfl_xor_u64(issued, d);
+        const uint32_t om = __shfl_xor(m, d, kWave);
+        m = om > m ? om : m;
+    }
+    const uint32_t w = threadIdx.x / kWave;
+    __syncthreads();                       // red may still be read from the previous call
+    if (lane_id() == 0) { red[w] = s; red[16 + w] = issued; red[32 + w] = m; }
     __syncthreads();
+    PcCheck r = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < kPcThreads / kWave; ++i) {
+        r.sum += red[i];
+        r.issued += red[16 + i];
+        r.max = (uint32_t)red[32 + i] > r.max ? (uint32_t)red[32 + i] : r.max;
+    }
+    return r;
+}
 
-    // The main loop handles the FULL 16-byte vectors; the ragged tail (< 16
-    // bytes, plus the pair that straddles into it) is left to one thread.
-    const uint64_t n_full = n / 16;
-    uint64_t per = (n_full + gridDim.x - 1) / gridDim.x;
-    per = (per + kPcThreads - 1) / kPcThreads * kPcThreads;
-    const uint64_t v_begin = per * blockIdx.x;
-    uint64_t v_end = v_begin + per;
-    if (v_end > n_full) v_end = n_full;
+// Counts the pairs that start in the full 16-byte vectors [begin, end) of this workgroup
+// (begin, end: multiples of the iteration size from the workgroup's first vector).  VPL vectors per
+// lane and iteration; SWEEPS: sweep every kPcEpochIters iterations (VPL must be 1).  Returns the number
+// of increments this lane issued.
+template <bool MASKED, int VPL, bool SWEEPS>
+__device__ __forceinline__ uint32_t pc_count_range(uint32_t *hist, uint32_t *__restrict__ bp,
+                                                   const uint8_t *__restrict__ text,
+                                                   const uint8_t *__restrict__ endmask, uint64_t n, uint64_t n_full,
+                                                   uint64_t wg_end, uint64_t begin, uint64_t end) {
+    static_assert(!SWEEPS || VPL == 1, "the slow loop sweeps every 3 x 16,384 increments");
+    constexpr uint64_t kIterVecs = (uint64_t)kPcThreads * VPL;
     const uint32_t lane = lane_id();
     const uint64_t last_vec = n_full ? n_full - 1 : 0;
-
-    // software pipeline: q/e/xb hold the vector of the NEXT iteration.  All
+    // software pipeline: q/e/xb hold the vectors of the NEXT iteration.  All
     // loads are unconditional (clamped addresses): a branch around a load or
     // an LDS atomic makes hipcc serialise them with full waits.
-    uint4 q = make_uint4(0, 0, 0, 0);
-    uint32_t e = 0, xb = 0;
+    uint4 q[VPL];
+    uint32_t e[VPL], xb[VPL];
     auto issue = [&](uint64_t base) {
-        uint64_t vec = base + threadIdx.x;
-        vec = vec < last_vec ? vec : last_vec;
-        const uint64_t byte0 = vec * 16;
-        q = *reinterpret_cast<const uint4 *>(text + byte0);
-        if (MASKED) e = reinterpret_cast<const uint16_t *>(endmask)[vec];
-        const uint64_t nx = byte0 + 16 < n ? byte0 + 16 : n - 1;
-        xb = text[lane == kWave - 1 ? nx : byte0];     // only lane 63 uses it
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) {
+            uint64_t vec = base + (uint64_t)u * kPcThreads + threadIdx.x;
+            vec = vec < last_vec ? vec : last_vec;
+            const uint64_t byte0 = vec * 16;
+            q[u] = *reinterpret_cast<const uint4 *>(text + byte0);
+            e[u] = MASKED ? reinterpret_cast<const uint16_t *>(endmask)[vec] : 0u;
+            const uint64_t nx = byte0 + 16 < n ? byte0 + 16 : n - 1;
+            xb[u] = text[lane == kWave - 1 ? nx : byte0];     // only lane 63 uses it
+        }
     };
-    if (v_begin < v_end) issue(v_begin);
-
+    uint32_t issued = 0;
+    if (begin < end) issue(begin);
     int epoch_iter = 0;
-    for (uint64_t base = v_begin; base < v_end; base += kPcThreads) {
-        const uint4 cq = q;
-        const uint32_t ce = e, cxb = xb;
-        issue(base + kPcThreads < v_end ? base + kPcThreads : base);
-
-        const uint64_t vec = base + threadIdx.x;
-        // first byte of the next lane's vector = second byte of my last pair
-        uint32_t nb = __shfl_down(cq.x, 1, kWave) & 0xFFu;
-        if (lane == kWave - 1) nb = cxb;
-        // pairs that start in this vector: 16, or 15 for the last full vector (its
-        // straddling pair belongs to the tail thread below)
-        uint32_t valid = vec < v_end ? (vec + 1 < n_full ? 0xFFFFu : 0x7FFFu) : 0u;
-        if (MASKED) valid &= ~ce;
-        const uint32_t w[5] = {cq.x, cq.y, cq.z, cq.w, nb};
-        if (__ballot(valid != 0xFFFFu) == 0ull) {
-            // every pair of every lane counts: no per-pair predicate
+    for (uint64_t base = begin; base < end; base += kIterVecs) {
+        uint4 cq[VPL];
+        uint32_t ce[VPL], cxb[VPL];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int wi = i >> 2, sh = 8 * (i & 3);
-                uint32_t bin;
-                if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
-                else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
-                bin ^= bin >> 8;
-                atomicAdd(&hist[bin & 0x7FFFu], 1u + (bin >> 15) * 0xFFFFu);
-            }
-        } else {
+        for (int u = 0; u < VPL; ++u) { cq[u] = q[u]; ce[u] = e[u]; cxb[u] = xb[u]; }
+        issue(base + kIterVecs < end ? base + kIterVecs : base);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int wi = i >> 2, sh = 8 * (i & 3);
-                uint32_t bin;
-                if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
-                else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
-                bin ^= bin >> 8;
-                const uint32_t inc = ((valid >> i) & 1u) ? 1u + (bin >> 15) * 0xFFFFu : 0u;   // invalid: add 0
-                atomicAdd(&hist[bin & 0x7FFFu], inc);
+        for (int u = 0; u < VPL; ++u) {
+            const uint64_t vec = base + (uint64_t)u * kPcThreads + threadIdx.x;
+            // first byte of the next lane's vector = second byte of my last pair
+            uint32_t nb = __shfl_down(cq[u].x, 1, kWave) & 0xFFu;
+            if (lane == kWave - 1) nb = cxb[u];
+            // pairs that start in this vector: 16, or 15 for the last full vector (its
+            // straddling pair belongs to the tail thread of the kernel)
+            uint32_t valid = vec < wg_end ? (vec + 1 < n_full ? 0xFFFFu : 0x7FFFu) : 0u;
+            if (MASKED) valid &= ~ce[u];
+            issued += __popc(valid);
+            const uint32_t w[5] = {cq[u].x, cq[u].y, cq[u].z, cq[u].w, nb};
+            if (__ballot(valid != 0xFFFFu) == 0ull) {
+                // every pair of every lane counts: no per-pair predicate
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int wi = i >> 2, sh = 8 * (i & 3);
+                    uint32_t bin;
+                    if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
+                    else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
+                    bin ^= bin >> 8;
+                    atomicAdd(&hist[bin & 0x7FFFu], 1u + (bin >> 15) * 0xFFFFu);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int wi = i >> 2, sh = 8 * (i & 3);
+                    uint32_t bin;
+                    if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
+                    else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
+                    bin ^= bin >> 8;
+                    const uint32_t inc = ((valid >> i) & 1u) ? 1u + (bin >> 15) * 0xFFFFu : 0u;   // invalid: add 0
+                    atomicAdd(&hist[bin & 0x7FFFu], inc);
+                }
             }
         }
-        if (++epoch_iter == kPcEpochIters) {
+        if (SWEEPS && ++epoch_iter == kPcEpochIters) {
             epoch_iter = 0;
             __syncthreads();
             pc_sweep(hist, bp);
             __syncthreads();
         }
+    }
+    return issued;
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__restrict__ text, uint64_t n,
+                                                              const uint8_t *__restrict__ endmask,
+                                                              uint32_t *__restrict__ bp,
+                                                              uint32_t *__restrict__ snap /* [gridDim.x][kPcWords] */) {
+    __shared__ uint32_t hist[kPcWords];
+    __shared__ unsigned long long red[48];
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kPcWords; w += kPcThreads) hist[w] = 0;
+    __syncthreads();
+
+    // The loops handle the FULL 16-byte vectors; the ragged tail (< 16
+    // bytes, plus the pair that straddles into it) is left to one thread.
+    constexpr uint64_t kIterVecs = (uint64_t)kPcThreads * kPcVpl;
+    const uint64_t n_full = n / 16;
+    uint64_t per = (n_full + gridDim.x - 1) / gridDim.x;
+    per = (per + kIterVecs - 1) / kIterVecs * kIterVecs;
+    const uint64_t v_begin = per * blockIdx.x;
+    uint64_t v_end = v_begin + per;
+    if (v_end > n_full) v_end = n_full;
+    uint4 *my_snap = reinterpret_cast<uint4 *>(snap + (size_t)blockIdx.x * kPcWords);
+
+    unsigned long long resid = 0;          // decoded sum of the counters (uniform)
+    uint32_t seg_iters = kPcSeg0;
+    for (uint64_t seg = v_begin; seg < v_end;) {
+        // (segment ends stay on iteration boundaries; the last one is cut at v_end)
+        const uint64_t seg_end = seg + seg_iters * kIterVecs < v_end ? seg + seg_iters * kIterVecs : v_end;
+        if (resid) {                       // something to lose: snapshot
+#pragma unroll
+            for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k)
+                my_snap[k * kPcThreads + threadIdx.x] = reinterpret_cast<const uint4 *>(hist)[k * kPcThreads + threadIdx.x];
+        }
+        const uint32_t issued = pc_count_range<MASKED, kPcVpl, false>(hist, bp, text, endmask, n, n_full, v_end, seg, seg_end);
+        __syncthreads();
+        PcCheck ck = pc_check(hist, issued, red);
+        if (ck.sum == resid + ck.issued) {
+            // exact.  Keep every counter below 0x2000 between segments
+            if (ck.max >= 0x2000u) {
+                pc_sweep(hist, bp);
+                __syncthreads();
+                ck = pc_check(hist, 0, red);
+            }
+            resid = ck.sum;
+            if (ck.max < 0x1000u && seg_iters < kPcSegMax) seg_iters *= 2;
+            else if (ck.max >= 0x8000u && seg_iters > 4) seg_iters /= 2;
+        } else {
+            // a counter wrapped: the segment is void.  Restore and recount it with sweeps
+#pragma unroll
+            for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k)
+                reinterpret_cast<uint4 *>(hist)[k * kPcThreads + threadIdx.x] =
+                    resid ? my_snap[k * kPcThreads + threadIdx.x] : make_uint4(0, 0, 0, 0);
+            __syncthreads();
+            pc_count_range<MASKED, 1, true>(hist, bp, text, endmask, n, n_full, v_end, seg, seg_end);
+            __syncthreads();
+            pc_sweep(hist, bp);
+            __syncthreads();
+            resid = pc_check(hist, 0, red).sum;
+            seg_iters = kPcSeg0;
+        }
+        seg = seg_end;
     }
     __syncthreads();
     pc_flush(hist, bp);
@@ -743,11 +874,6 @@ __device__ __forceinline__ Top2 top2_merge(Top2 a, unsigned long long bv1, unsig
     return r;
 }
 
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int d) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, d, kWave), hi = __shfl_xor((uint32_t)(v >> 32), d, kWave);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 // Largest and second largest of 1024 values over the workgroup (all threads get
 // the result): thread t holds the values of indices base + q * 256 + t, q < 4.
 __device__ Top2 block_top2(const unsigned long long v[kHierItems], uint32_t base, Top2 *sh) {
@@ -821,6 +947,158 @@ __global__ __launch_bounds__(kHierThreads) void k_argmax_hier(PairTable t, const
         }
         __syncthreads();
     }
+}
+
+// ---- `first` tie-break (insertion order) ---------------------------------------------
+// The reference's default mode (minbpe-cc.cpp:129-131) rebuilds the pair table before every merge
+// (Tokenizer.h:581-585) in a PairCountInsertOrder (PairCount.h:101-181): among the pairs of maximal
+// count the one inserted first wins (CompareCountOrder, PairCount.h:65-74), i.e. the one whose first
+// occurrence comes first in scan order (calculate_freqs walks the chunks front to back,
+// Tokenizer.h:135-144).  The counts of a rebuilt table are the exact overlapping-window counts, which
+// is what the incrementally maintained table holds (SURVEY.md 8-S rule 3), so no recount is needed:
+//   k_argmax[_hier]   max count M (and the lexical winner among the pairs that have it)
+//   k_first_gather    how many pairs have count M; a bitmap of their hashed keys
+//   k_first_pos       only when several do: the smallest stream position at which one of them
+//                     starts -- one wave per tile in stream order, waves stop at the first tile beyond
+//                     the best position found so far (many ties: the answer is near the front; few
+//                     ties: the bitmap rejects nearly every pair before the table is consulted)
+//   k_first_pick      replaces best[k] by (M, that pair)
+// A table rebuilt from scratch has no zero-count pairs: max count 0 means "no pair left", where the
+// reference's loop breaks (Tokenizer.h:586-588); mbpe_train_result cuts the merges there.
+constexpr uint32_t kFirstBitmapWords = 2048;          // 64 Ki bits
+struct FirstState {
+    unsigned long long pos_key;      // (slot position << 32) | key of the earliest tied pair; ~0: none yet
+    uint32_t n_tie;                  // pairs whose count is the maximum
+    uint32_t pad;
+    uint32_t bitmap[kFirstBitmapWords];
+};
+
+__device__ __forceinline__ uint32_t first_hash(uint32_t key) { return hash_key(key) >> 16; }
+
+// count of `key`, or 0xFFFFFFFF when the pair was never inserted
+__device__ __forceinline__ uint32_t table_lookup(const PairTable &t, uint32_t key) {
+    if (t.cells) {
+        const uint32_t v = t.cells[dense_index(t, key)];
+        return (v & kPresent) ? (v & ~kPresent) : 0xFFFFFFFFu;
+    }
+    uint32_t h = hash_key(key) & t.hmask;
+    for (uint32_t probe = 0; probe <= t.hmask; ++probe) {
+        const unsigned long long slot = t.hslot[h];
+        if ((uint32_t)(slot >> 32) == key) {
+            const int32_t c = t.ecnt[(uint32_t)slot];
+            return c < 0 ? 0u : (uint32_t)c;
+        }
+        if (slot == kEmptySlot) return 0xFFFFFFFFu;
+        h = (h + 1) & t.hmask;
+    }
+    return 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void k_first_gather(PairTable t, const DevCtl *ctl,
+                                                      const unsigned long long *__restrict__ best_ptr,
+                                                      FirstState *fs) {
+    const unsigned long long best = *best_ptr;
+    const uint32_t M = (uint32_t)(best >> 32);
+    if (M == 0) return;
+    const unsigned long long T = (unsigned long long)M << 32;
+    const uint32_t n = table_size(t, ctl);
+    const uint32_t n_blocks = (n + kBlockSize - 1) >> kBlockShift;
+    const uint32_t lane = lane_id();
+    const uint32_t n_waves = gridDim.x * (blockDim.x / kWave);
+    uint32_t found = 0;
+    for (uint32_t B = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; B < n_blocks; B += n_waves) {
+        if (t.bmax[B] < T) continue;          // an upper bound of the block's packed values
+#pragma unroll 4
+        for (uint32_t q = 0; q < kBlockSize / kWave; ++q) {
+            const uint32_t e = (B << kBlockShift) + q * kWave + lane;
+            const unsigned long long p = e < n ? entry_packed(t, e) : 0ull;
+            if ((uint32_t)(p >> 32) == M) {
+                const uint32_t hb = first_hash(~(uint32_t)p);
+                atomicOr(&fs->bitmap[hb >> 5], 1u << (hb & 31u));
+                ++found;
+            }
+        }
+    }
+    found = wave_sum(found);
+    if (lane == 0 && found) atomicAdd(&fs->n_tie, found);
+}
+
+template <bool CHUNKED>
+__global__ __launch_bounds__(kMergeThreads) void k_first_pos(const uint16_t *__restrict__ tok,
+                                                             const TileSum *__restrict__ sin, uint32_t n_tiles,
+                                                             PairTable t,
+                                                             const unsigned long long *__restrict__ best_ptr,
+                                                             FirstState *fs) {
+    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    __shared__ uint32_t bm[kFirstBitmapWords];
+    if (fs->n_tie <= 1) return;                           // a unique maximum: position does not matter
+    const uint32_t M = (uint32_t)(*best_ptr >> 32);
+    for (uint32_t i = threadIdx.x; i < kFirstBitmapWords; i += kMergeThreads) bm[i] = fs->bitmap[i];
+    __syncthreads();
+    const uint32_t lane = lane_id();
+    const uint32_t waves_per_block = kMergeThreads / kWave;
+    const uint32_t n_waves = gridDim.x * waves_per_block;
+    const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    for (uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave); tile < n_tiles; tile += n_waves) {
+        // tiles are visited in ascending order: nothing at or after this one can win any more
+        const unsigned long long cur = __hip_atomic_load(&fs->pos_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((cur >> 32) < (unsigned long long)tile * kTile) break;
+        const uint4 q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kWave + lane];
+        uint32_t s[8];
+        unpack8(q, s);
+        uint32_t cnt = 0, f1 = kHole;
+#pragma unroll
+        for (int j = 7; j >= 0; --j)
+            if (s[j] != kHole) { f1 = s[j]; ++cnt; }
+        const unsigned long long m_live = __ballot(cnt > 0);
+        if (!m_live) continue;
+        // first live token after this tile (only the last live lane needs it)
+        uint32_t after = kHole;
+        for (uint32_t j = tile + 1; j < n_tiles; ++j) {
+            const TileSum ns = sin[j];
+            if (ns.n_live) { after = ns.head0; break; }
+        }
+        const unsigned long long hi = m_live & gt_mask;
+        const uint32_t src = hi ? (uint32_t)__builtin_ctzll(hi) : lane;
+        const uint32_t nf = __shfl(f1, src, kWave);
+        uint32_t nx = hi ? nf : after;                    // next live token after this lane's slots
+        uint32_t my_pos = 0xFFFFFFFFu, my_key = 0;
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            const uint32_t self = s[j];
+            if (self == kHole) continue;
+            if (nx != kHole && !(self & endbit)) {        // a pair starts here (Tokenizer.h:135-144)
+                const uint32_t key = ((self & idmask) << 16) | (nx & idmask);
+                const uint32_t hb = first_hash(key);
+                if ((bm[hb >> 5] >> (hb & 31u)) & 1u) {
+                    if (table_lookup(t, key) == M) { my_pos = lane * 8u + j; my_key = key; }
+                }
+            }
+            nx = self;
+        }
+        const unsigned long long hit = __ballot(my_pos != 0xFFFFFFFFu);
+        if (hit) {
+            const uint32_t w = (uint32_t)__builtin_ctzll(hit);           // lowest lane = earliest position
+            const uint32_t pos = rlane(my_pos, w), key = rlane(my_key, w);
+            if (lane == 0)
+                atomicMin(&fs->pos_key, (((unsigned long long)tile * kTile + pos) << 32) | key);
+            break;                                        // every later tile of this wave lies behind it
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_first_pick(unsigned long long *best_ptr, FirstState *fs) {
+    __shared__ unsigned long long pk;
+    __shared__ uint32_t nt;
+    if (threadIdx.x == 0) { pk = fs->pos_key; nt = fs->n_tie; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (nt > 1 && pk != ~0ull) *best_ptr = pack_best((int32_t)(*best_ptr >> 32), (uint32_t)pk);
+        fs->pos_key = ~0ull;
+        fs->n_tie = 0;
+    }
+    if (nt) for (uint32_t i = threadIdx.x; i < kFirstBitmapWords; i += blockDim.x) fs->bitmap[i] = 0;
 }
 
 // ---- table init / rehash -------------------------------------------------------
@@ -3153,17 +3431,19 @@ void launch_fill_u16(hipStream_t s, uint16_t *p, uint64_t n, uint16_t v) {
     hipLaunchKernelGGL(k_fill_u16, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, s, p, n, v);
 }
 
+size_t pair_count_scratch_bytes(int n_workgroups) { return (size_t)(n_workgroups < 1 ? 1 : n_workgroups) * kPcWords * 4; }
+
 void launch_pair_count_u8(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask,
-                          uint32_t *bp, int n_workgroups) {
+                          uint32_t *bp, int n_workgroups, uint32_t *scratch) {
     if (n < 2) return;
     uint64_t n_vec = n / 16;
-    uint64_t max_wg = (n_vec + kPcThreads - 1) / kPcThreads;
+    uint64_t max_wg = (n_vec + kPcThreads * kPcVpl - 1) / (kPcThreads * kPcVpl);
     if ((uint64_t)n_workgroups > max_wg) n_workgroups = (int)max_wg;
     if (n_workgroups < 1) n_workgroups = 1;
     if (endmask)
-        hipLaunchKernelGGL(k_pair_count_u8<true>, dim3(n_workgroups), dim3(kPcThreads), 0, s, text, n, endmask, bp);
+        hipLaunchKernelGGL(k_pair_count_u8<true>, dim3(n_workgroups), dim3(kPcThreads), 0, s, text, n, endmask, bp, scratch);
     else
-        hipLaunchKernelGGL(k_pair_count_u8<false>, dim3(n_workgroups), dim3(kPcThreads), 0, s, text, n, endmask, bp);
+        hipLaunchKernelGGL(k_pair_count_u8<false>, dim3(n_workgroups), dim3(kPcThreads), 0, s, text, n, endmask, bp, scratch);
 }
 
 void launch_widen(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask, uint16_t *tok,
@@ -3196,6 +3476,26 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
     }
     int blocks = blocks_for(t.ecap, kArgmaxThreads * 4, 1024);
     hipLaunchKernelGGL(k_argmax, dim3(blocks), dim3(kArgmaxThreads), 0, s, t, ctl, best);
+}
+
+size_t first_state_bytes() { return sizeof(FirstState); }
+
+void launch_first_init(hipStream_t s, void *fs) {
+    (void)hipMemsetAsync(fs, 0, sizeof(FirstState), s);
+    (void)hipMemsetAsync(fs, 0xFF, 8, s);          // pos_key = ~0
+}
+
+void launch_first_tiebreak(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best, void *fs_,
+                           const uint16_t *tok, const TileSum *sums, uint32_t n_tiles, uint32_t endbit, int n_cus) {
+    FirstState *fs = static_cast<FirstState *>(fs_);
+    const uint32_t n_blocks = (t.ecap + kBlockSize - 1) >> kBlockShift;
+    hipLaunchKernelGGL(k_first_gather, dim3(blocks_for(n_blocks, 4, 2048)), dim3(256), 0, s, t, ctl, best, fs);
+    if (n_tiles) {
+        const dim3 grid(tile_grid(n_tiles, n_cus, 8)), block(kMergeThreads);
+        if (endbit) hipLaunchKernelGGL(k_first_pos<true>, grid, block, 0, s, tok, sums, n_tiles, t, best, fs);
+        else hipLaunchKernelGGL(k_first_pos<false>, grid, block, 0, s, tok, sums, n_tiles, t, best, fs);
+    }
+    hipLaunchKernelGGL(k_first_pick, dim3(1), dim3(256), 0, s, best, fs);
 }
 
 void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileSum *sin, TileSum *sout, uint32_t n_tiles,

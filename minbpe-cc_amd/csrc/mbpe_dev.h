@@ -200,8 +200,10 @@ void launch_fill_u16(hipStream_t s, uint16_t *p, uint64_t n, uint16_t v);
 
 // pair-count scan over the byte corpus. endmask: bit i set = byte i is the
 // last byte of its chunk (NULL for a one-chunk corpus). bp[first<<8|second].
+// scratch: pair_count_scratch_bytes(n_workgroups) of device memory (per-workgroup histogram snapshots)
+size_t pair_count_scratch_bytes(int n_workgroups);
 void launch_pair_count_u8(hipStream_t s, const uint8_t *text, uint64_t n,
-                          const uint8_t *endmask, uint32_t *bp, int n_workgroups);
+                          const uint8_t *endmask, uint32_t *bp, int n_workgroups, uint32_t *scratch);
 
 // u8 corpus -> 16-bit slot stream (+END flags), padded to whole tiles with holes
 void launch_widen(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask,
@@ -218,6 +220,14 @@ void launch_table_rehash(hipStream_t s, PairTable t, DevCtl *ctl);
 // best[0] = max over entries of pack_best(count, key)   (best must be zeroed)
 // hierarchical = one workgroup walking the block bounds (large tables); else a full scan
 void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best, bool hierarchical);
+
+// `first` tie-break (reference PairCountInsertOrder, PairCount.h:65-74, :101-181): after the argmax wrote
+// best[0] = (max count, lexical winner), replace it by the pair of that count whose first occurrence in
+// the stream comes first.  fs: first_state_bytes() of device memory, prepared once by launch_first_init.
+size_t first_state_bytes();
+void launch_first_init(hipStream_t s, void *fs);
+void launch_first_tiebreak(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best, void *fs,
+                           const uint16_t *tok, const TileSum *sums, uint32_t n_tiles, uint32_t endbit, int n_cus);
 
 // one merge pass over the stream, in place; new summaries of changed tiles go
 // to `side`, their bits are set in `chg` (launch_apply folds them into sums)

@@ -126,6 +126,9 @@ struct mbpe_ctx {
     bool loaded = false;
     bool inert = false;          // whole corpus collapses to one token (NUL quirk, basic)
 
+    uint32_t *pc_scratch = nullptr;   // pair-count scan: per-workgroup histogram snapshots (kept for the context's life)
+    void *first_state = nullptr;      // `first` tie-break scratch (training)
+
     // slot stream
     uint16_t *tok[2] = {nullptr, nullptr};
     int cur = 0;
@@ -186,6 +189,7 @@ struct mbpe_ctx {
     int64_t opt_sel_cap = kSelCap;      // candidate-list capacity (tests lower it to force the overflow path)
     int64_t opt_threshold_select = 1;   // 0: always select with the bound-walking kernel
     int64_t opt_dense_table = -1;   // -1 auto / 1: dense pair table when vocab <= 32,768; 0: always hashed
+    int64_t opt_first = 0;          // 1: `first` tie-break (insertion order, PairCount.h:65-74) instead of lexical
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
     std::vector<hipEvent_t> kev_f;  // ... around the fused pass alone
@@ -222,6 +226,7 @@ void free_training(mbpe_ctx *c) {
     dfree(c->tab.bmax); dfree(c->tab.smax);
     dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->xb); dfree(c->xb0);
     dfree(c->d_left); dfree(c->d_right); dfree(c->bs); dfree(c->sel); dfree(c->seq_flags); dfree(c->run_in);
+    if (c->first_state) { (void)hipFree(c->first_state); c->first_state = nullptr; }
     c->LR = nullptr;
     c->pending = 0;
     c->begun = false;
@@ -323,6 +328,11 @@ int grow_table(mbpe_ctx *c, uint64_t want) {
     return MBPE_OK;
 }
 
+int ensure_pc_scratch(mbpe_ctx *c) {
+    if (!c->pc_scratch) HIPCHK(hipMalloc(&c->pc_scratch, pair_count_scratch_bytes(c->n_cus)));
+    return MBPE_OK;
+}
+
 int do_compact(mbpe_ctx *c) {
     // c->h_ctl must be current
     if (!c->n_tiles) return MBPE_OK;
@@ -383,6 +393,7 @@ void mbpe_destroy(mbpe_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_training(c);
     free_corpus(c);
+    dfree(c->pc_scratch);
     if (c->nccl_comm && rccl().ok) rccl().CommDestroy(c->nccl_comm);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->kev_f) (void)hipEventDestroy(e);
@@ -406,6 +417,11 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "fused_min") c->opt_fused_min = std::max<int64_t>(2, value);
     else if (n == "dense_table") c->opt_dense_table = value;
     else if (n == "threshold_select") c->opt_threshold_select = value != 0;
+    else if (n == "conflict_resolution") {
+        if (value != 0 && value != 1) { mbpe_host::set_last_error("conflict_resolution: 0 = first, 1 = lexical"); return MBPE_ERR_ARG; }
+        if (c->begun) { mbpe_host::set_last_error("conflict_resolution must be set before mbpe_train_begin"); return MBPE_ERR_STATE; }
+        c->opt_first = value == 0;
+    }
     else if (n == "sel_cap") c->opt_sel_cap = std::min<int64_t>(std::max<int64_t>(64, value), kSelCap);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
@@ -506,11 +522,13 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
     if (!c) return MBPE_ERR_ARG;
     if (!c->loaded) { mbpe_host::set_last_error("mbpe_pair_count_u8: no corpus loaded"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
+    int rcs = ensure_pc_scratch(c);
+    if (rcs != MBPE_OK) return rcs;
     uint32_t *bp = nullptr;
     HIPCHK(hipMalloc(&bp, 65536 * 4));
     HIPCHK(hipMemsetAsync(bp, 0, 65536 * 4, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    if (!c->inert) launch_pair_count_u8(c->stream, c->d_text, c->n_bytes, c->d_endmask, bp, c->n_cus);
+    if (!c->inert) launch_pair_count_u8(c->stream, c->d_text, c->n_bytes, c->d_endmask, bp, c->n_cus, c->pc_scratch);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipGetLastError();
@@ -574,6 +592,10 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(hipMalloc(&c->run_in, ((size_t)c->n_tiles + 64) * 4));
     HIPCHK(hipMalloc(&c->seq_flags, 4096 * 4));
     HIPCHK(hipMemsetAsync(c->bs, 0, sizeof(BatchState), c->stream));
+    if (c->opt_first) {
+        HIPCHK(hipMalloc(&c->first_state, first_state_bytes()));
+        launch_first_init(c->stream, c->first_state);
+    }
     c->k_upper = 0;
     c->bp = nullptr;   // the byte-pair table lives at the front of xb0
     HIPCHK(hipMalloc(&c->d_left, sizeof(RankEdge)));
@@ -598,8 +620,10 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     int rc = use_dense(c) ? alloc_table_dense(c) : alloc_table(c, (uint32_t)want);
     if (rc != MBPE_OK) return rc;
 
+    rc = ensure_pc_scratch(c);
+    if (rc != MBPE_OK) return rc;
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    if (n >= 2) launch_pair_count_u8(c->stream, c->d_text, n, c->d_endmask, c->xb0, c->n_cus);
+    if (n >= 2) launch_pair_count_u8(c->stream, c->d_text, n, c->d_endmask, c->xb0, c->n_cus, c->pc_scratch);
     c->cur = 0;
     launch_widen(c->stream, c->d_text, n, c->d_endmask, c->tok[0], c->n_slots);
     launch_summarize(c->stream, c->tok[0], c->sums, c->n_tiles, c->n_cus);
@@ -619,6 +643,9 @@ static int begin_finish(mbpe_ctx *c) {
     }
     launch_table_init(c->stream, c->xb0, c->tab, c->ctl);
     launch_argmax(c->stream, c->tab, c->ctl, c->best, use_hier(c));
+    if (c->opt_first)
+        launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best, c->first_state, c->tok[c->cur], c->sums, c->n_tiles,
+                              endbit, c->n_cus);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     int rc = sync_ctl(c);
     if (rc != MBPE_OK) return rc;
@@ -655,6 +682,9 @@ static void step_finish(mbpe_ctx *c) {
                  c->chg, c->n_tiles, 0);
     if (multi) launch_compose_edges(c->stream, c->xb, c->rank, c->n_ranks, c->d_left, c->d_right);
     launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1, use_hier(c));
+    if (c->opt_first)
+        launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best + c->k + 1, c->first_state, c->tok[c->cur], c->sums,
+                              c->n_tiles, c->chunked ? kEndBit : 0, c->n_cus);
     c->k++;
 }
 
@@ -668,7 +698,8 @@ static size_t step_exchange_words(const mbpe_ctx *c) { return exchange_words(c, 
 // The merge counter lives on the device (ctl->k_done); the host only keeps an
 // upper bound (k_upper) between synchronisations.
 
-static inline bool use_batches(const mbpe_ctx *c) { return c->opt_multi_merge != 0; }
+// (`first` mode decides every merge by stream position: one merge per pass)
+static inline bool use_batches(const mbpe_ctx *c) { return c->opt_multi_merge != 0 && !c->opt_first; }
 
 static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exchange
     const uint32_t endbit = c->chunked ? kEndBit : 0;
@@ -755,6 +786,10 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     if (vocab_size > vmax) {
         mbpe_host::set_last_error("vocab_size exceeds the 16-bit slot format (" + std::to_string(vmax) + ")");
         return MBPE_ERR_VOCAB;
+    }
+    if (c->opt_first && (is_multi(c) || c->n_bytes >= 0xFFFFFE00ull)) {
+        mbpe_host::set_last_error("conflict_resolution first: one GPU and a corpus below 4 GiB only");
+        return MBPE_ERR_STATE;
     }
     HIPCHK(hipSetDevice(c->device));
     int rc = begin_local(c, vocab_size);
@@ -1020,12 +1055,19 @@ int mbpe_train_result(mbpe_ctx *c, uint32_t *merges_out, int32_t *counts_out, ui
     if (!c) return MBPE_ERR_ARG;
     if (!c->begun) { mbpe_host::set_last_error("mbpe_train_result before mbpe_train_begin"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
-    const uint32_t n = c->exhausted ? 0 : c->n_valid;
+    uint32_t n = c->exhausted ? 0 : c->n_valid;
+    std::vector<unsigned long long> h(n);
+    if (n) HIPCHK(hipMemcpy(h.data(), c->best, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (c->opt_first) {
+        // a table rebuilt before every merge holds no zero-count pair: the reference's loop breaks as soon as
+        // no pair is left (Tokenizer.h:586-588), the incremental table only shows it as "max count 0"
+        uint32_t real = 0;
+        while (real < n && (h[real] >> 32) != 0) ++real;
+        n = real;
+    }
     if (n_merges_out) *n_merges_out = n;
     if (n > cap_merges && merges_out) { mbpe_host::set_last_error("merges_out too small"); return MBPE_ERR_ARG; }
     if (!n || !merges_out) return MBPE_OK;
-    std::vector<unsigned long long> h(n);
-    HIPCHK(hipMemcpy(h.data(), c->best, (size_t)n * 8, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; ++i) {
         uint32_t key = ~(uint32_t)h[i];
         merges_out[2 * i] = key >> 16;
@@ -1060,20 +1102,31 @@ int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
     return MBPE_OK;
 }
 
+int mbpe_train(mbpe_ctx *c, const uint8_t *text, uint64_t n_bytes, const uint64_t *chunk_off, uint64_t n_chunks,
+               uint32_t vocab_size, int conflict_resolution, uint32_t *merges_out, int32_t *counts_out,
+               uint32_t *n_merges_out, mbpe_stats *stats_out) {
+    if (!c || !merges_out) { mbpe_host::set_last_error("mbpe_train: NULL argument"); return MBPE_ERR_ARG; }
+    if (conflict_resolution != 0 && conflict_resolution != 1) {
+        mbpe_host::set_last_error("conflict_resolution: 0 = first, 1 = lexical");
+        return MBPE_ERR_ARG;
+    }
+    int rc = mbpe_load_corpus(c, text, n_bytes, chunk_off, n_chunks, 0);
+    if (rc != MBPE_OK) return rc;
+    const int64_t keep = c->opt_first;
+    c->opt_first = conflict_resolution == 0;
+    rc = mbpe_train_begin(c, vocab_size);
+    if (rc == MBPE_OK) rc = mbpe_train_steps(c, vocab_size - 256, nullptr);
+    if (rc == MBPE_OK) rc = mbpe_train_result(c, merges_out, counts_out, vocab_size - 256, n_merges_out);
+    if (rc == MBPE_OK && stats_out) mbpe_get_stats(c, stats_out);
+    c->opt_first = keep;
+    return rc;
+}
+
 int mbpe_train_lexical(mbpe_ctx *c, const uint8_t *text, uint64_t n_bytes, const uint64_t *chunk_off,
                        uint64_t n_chunks, uint32_t vocab_size, uint32_t *merges_out, int32_t *counts_out,
                        uint32_t *n_merges_out, mbpe_stats *stats_out) {
-    if (!c || !merges_out) { mbpe_host::set_last_error("mbpe_train_lexical: NULL argument"); return MBPE_ERR_ARG; }
-    int rc = mbpe_load_corpus(c, text, n_bytes, chunk_off, n_chunks, 0);
-    if (rc != MBPE_OK) return rc;
-    rc = mbpe_train_begin(c, vocab_size);
-    if (rc != MBPE_OK) return rc;
-    rc = mbpe_train_steps(c, vocab_size - 256, nullptr);
-    if (rc != MBPE_OK) return rc;
-    rc = mbpe_train_result(c, merges_out, counts_out, vocab_size - 256, n_merges_out);
-    if (rc != MBPE_OK) return rc;
-    if (stats_out) mbpe_get_stats(c, stats_out);
-    return MBPE_OK;
+    return mbpe_train(c, text, n_bytes, chunk_off, n_chunks, vocab_size, 1, merges_out, counts_out, n_merges_out,
+                      stats_out);
 }
 
 int mbpe_get_stream(mbpe_ctx *c, uint32_t *tokens_out, uint8_t *chunk_end_out, uint64_t cap, uint64_t *n_out) {
@@ -1109,6 +1162,18 @@ int mbpe_stream_device(mbpe_ctx *c, const void **slots_out, uint64_t *n_slots_ou
     *n_slots_out = c->n_slots;
     if (slot_bits_out) *slot_bits_out = 16;
     if (end_bit_out) *end_bit_out = c->chunked ? kEndBit : 0;
+    return MBPE_OK;
+}
+
+int mbpe_table_device(mbpe_ctx *c, const void **cells_out, uint32_t *vshift_out) {
+    if (!c || !cells_out || !vshift_out) return MBPE_ERR_ARG;
+    if (!c->begun) { mbpe_host::set_last_error("mbpe_table_device before mbpe_train_begin"); return MBPE_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = sync_ctl(c);
+    if (rc != MBPE_OK) return rc;
+    if (!c->tab.cells) { mbpe_host::set_last_error("the pair table is hashed (no dense view)"); return MBPE_ERR_STATE; }
+    *cells_out = c->tab.cells;
+    *vshift_out = c->tab.vshift;
     return MBPE_OK;
 }
 

@@ -82,10 +82,6 @@ void Tokenizer::set_special_tokens_from_file(const std::string &input_string) { 
 void Tokenizer::train(const std::string &text, int vocab_size, CONFLICT_RESOLUTION conflict_resolution,
                       bool verbose, int device) {
     if (vocab_size < 256) throw std::runtime_error("vocab_size must be >= 256");   // assert, :492
-    if (conflict_resolution != LEXICAL)
-        throw std::runtime_error(
-            "conflict resolution 'first' (full recount per merge, Tokenizer.h:581-585) is the reference's slow "
-            "path and is not provided by the MI355X build: use 'lexical'");
     merges_.clear();
     merges_lookup_.clear();
     initialize_vocab();
@@ -114,9 +110,9 @@ void Tokenizer::train(const std::string &text, int vocab_size, CONFLICT_RESOLUTI
     std::vector<int32_t> had(cap + 1);
     uint32_t n_merges = 0;
     mbpe_stats st;
-    int rc = mbpe_train_lexical(ctx, bytes, text.size(), chunked ? off.data() : nullptr,
-                                chunked ? off.size() - 1 : 0, static_cast<uint32_t>(vocab_size), flat.data(),
-                                had.data(), &n_merges, &st);
+    int rc = mbpe_train(ctx, bytes, text.size(), chunked ? off.data() : nullptr, chunked ? off.size() - 1 : 0,
+                        static_cast<uint32_t>(vocab_size), conflict_resolution == LEXICAL ? 1 : 0, flat.data(),
+                        had.data(), &n_merges, &st);
     std::string msg = rc == MBPE_OK ? "" : mbpe_last_error();
     mbpe_destroy(ctx);
     if (rc != MBPE_OK) throw std::runtime_error(msg);

@@ -28,7 +28,7 @@ public:
     Tokenizer &operator=(const Tokenizer &) = delete;
 
     void set_special_tokens_from_file(const std::string &input_string);   // :476-486
-    // :489-598; LEXICAL runs on HIP device `device`; FIRST throws std::runtime_error
+    // :489-598; both CONFLICT_RESOLUTION values run on HIP device `device` (mbpe_train)
     void train(const std::string &text, int vocab_size, CONFLICT_RESOLUTION conflict_resolution, bool verbose,
                int device = 0);
     std::vector<Token> encode(const std::string &text, bool verbose);      // :653-722

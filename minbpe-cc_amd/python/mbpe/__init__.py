@@ -22,7 +22,7 @@ COMM_ID_BYTES = 128
 EXPORTS = [
     "mbpe_last_error", "mbpe_version", "mbpe_create", "mbpe_destroy", "mbpe_load_corpus",
     "mbpe_pair_count_u8", "mbpe_train_begin", "mbpe_train_steps", "mbpe_train_sequences", "mbpe_train_result",
-    "mbpe_train_lexical", "mbpe_get_stats", "mbpe_get_stream", "mbpe_stream_device", "mbpe_get_pairs", "mbpe_compact",
+    "mbpe_train_lexical", "mbpe_train", "mbpe_get_stats", "mbpe_get_stream", "mbpe_stream_device", "mbpe_table_device", "mbpe_get_pairs", "mbpe_compact",
     "mbpe_set_option", "mbpe_comm_unique_id", "mbpe_comm_init", "mbpe_comm_init_external",
     "mbpe_comm_exchange_buffer", "mbpe_comm_exchange_done", "mbpe_presplit",
     "mbpe_split_count", "mbpe_split_offsets", "mbpe_split_free", "mbpe_split_pattern",
@@ -86,9 +86,11 @@ def lib():
     L.mbpe_train_sequences.argtypes = [vp, u32, vp]
     L.mbpe_train_result.argtypes = [vp, vp, vp, u32, vp]
     L.mbpe_train_lexical.argtypes = [vp, vp, u64, vp, u64, u32, vp, vp, vp, vp]
+    L.mbpe_train.argtypes = [vp, vp, u64, vp, u64, u32, i32, vp, vp, vp, vp]
     L.mbpe_get_stats.argtypes = [vp, vp]
     L.mbpe_get_stream.argtypes = [vp, vp, vp, u64, vp]
     L.mbpe_stream_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.mbpe_table_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u32)]
     L.mbpe_get_pairs.argtypes = [vp, vp, vp, vp, u64, vp]
     L.mbpe_compact.argtypes = [vp]
     L.mbpe_set_option.argtypes = [vp, ctypes.c_char_p, i64]
@@ -245,6 +247,10 @@ class Trainer:
         return merges[:n.value].copy(), counts[:n.value].copy()
 
     def train_lexical(self, data, vocab_size, chunk_off=None):
+        return self.train(data, vocab_size, chunk_off, conflict_resolution=1)
+
+    def train(self, data, vocab_size, chunk_off=None, conflict_resolution=1):
+        """conflict_resolution: 1 = lexical, 0 = first (mbpe_train)."""
         text = _u8(data)
         off = None if chunk_off is None else np.ascontiguousarray(chunk_off, dtype=np.uint64)
         cap = max(vocab_size - 256, 1)
@@ -252,11 +258,11 @@ class Trainer:
         counts = np.zeros(cap, dtype=np.int32)
         n = ctypes.c_uint32()
         st = Stats()
-        _check(lib().mbpe_train_lexical(self._h, text.ctypes.data if len(text) else None, len(text),
-                                        None if off is None else off.ctypes.data,
-                                        0 if off is None else len(off) - 1, vocab_size,
-                                        merges.ctypes.data, counts.ctypes.data, ctypes.byref(n),
-                                        ctypes.byref(st)))
+        _check(lib().mbpe_train(self._h, text.ctypes.data if len(text) else None, len(text),
+                                None if off is None else off.ctypes.data,
+                                0 if off is None else len(off) - 1, vocab_size, conflict_resolution,
+                                merges.ctypes.data, counts.ctypes.data, ctypes.byref(n),
+                                ctypes.byref(st)))
         self.vocab_size = vocab_size
         return merges[:n.value].copy(), counts[:n.value].copy(), st.as_dict()
 
@@ -279,6 +285,12 @@ class Trainer:
         bits, end = ctypes.c_uint32(), ctypes.c_uint32()
         _check(lib().mbpe_stream_device(self._h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(bits), ctypes.byref(end)))
         return p.value, n.value, bits.value, end.value
+
+    def table_device(self):
+        """(device pointer, vshift) of the dense pair table (see mbpe_table_device)."""
+        p, v = ctypes.c_void_p(), ctypes.c_uint32()
+        _check(lib().mbpe_table_device(self._h, ctypes.byref(p), ctypes.byref(v)))
+        return p.value, v.value
 
     def pairs(self):
         n = ctypes.c_uint64()

@@ -118,3 +118,28 @@ def recount_pairs(tr, torch, device):
     u, c = torch.unique(key, return_counts=True)
     u, c = u.cpu().numpy(), c.cpu().numpy()
     return {(int(k >> 32), int(k & 0xFFFFFFFF)): int(v) for k, v in zip(u, c)}
+
+
+def dense_table_matches_recount(tr, torch, device):
+    """The incrementally maintained dense pair table against a recount of the live stream, on the device:
+    every pair of the stream has exactly its count in its cell, and no other cell holds a non-zero count."""
+    toks, ends = live_tokens(tr, torch, device)
+    ptr, vshift = tr.table_device()
+    cells = _as_tensor(torch, ptr, 1 << (2 * vshift), torch.int32, device)
+    a, b = toks[:-1].long(), toks[1:].long()
+    if ends is not None:
+        keep = ~ends[:-1]
+        a, b = a[keep], b[keep]
+    idx = ((((a >> 5) << (vshift - 5)) | (b >> 5)) << 10) | ((a & 31) << 5) | (b & 31)
+    del a, b
+    u, c = torch.unique(idx, return_counts=True)
+    del idx
+    got = cells[u].long() & 0x7FFFFFFF
+    present = bool(((cells[u].long() >> 31) & 1).all())
+    same = bool((got == c).all())
+    nonzero = 0
+    step = 1 << 28
+    for lo in range(0, cells.numel(), step):
+        nonzero += int(((cells[lo:lo + step] & 0x7FFFFFFF) != 0).sum())
+    return {"ok": present and same and nonzero == int(u.numel()), "pairs_in_stream": int(u.numel()),
+            "nonzero_cells": nonzero, "counts_equal": same, "all_present": present}

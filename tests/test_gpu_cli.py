@@ -49,10 +49,41 @@ def test_e2e_gpt4_config5(tmp_path):
     assert dec.read_bytes() == read_data("taylorswift.txt")
 
 
-def test_cli_first_mode_reports_unavailable(tmp_path):
-    r = subprocess.run([CLI, "-t", "-i", os.path.join(DATA, "small.txt"), "-m", str(tmp_path / "m"), "--encoder", "basic"],
-                       capture_output=True, text=True)    # default -c first
-    assert r.returncode == 255 and "lexical" in r.stderr
+def test_e2e_gpt4_first_special_tokens(tmp_path):
+    # endtoend-test.sh:13-16: the reference's second scenario, with the CLI's own defaults
+    # (--encoder gpt4, --conflict-resolution first, --vocab-size 512)
+    model, enc, dec = tmp_path / "gpt4-special-model", tmp_path / "enc", tmp_path / "dec"
+    special = os.path.join(DATA, "special1.txt")
+    out = _run("--train", "--input", os.path.join(DATA, "taylorswift.txt"), "--model-path", model,
+               "--special-tokens-path", special, "--encoder", "gpt4", "--conflict-resolution", "first")
+    assert "Writing model..." in out
+    got = mbpe_model_merges(model.read_bytes())
+    assert got == mbpe_model_merges(read_golden("taylorswift_gpt4_first_512.model"))
+    src = os.path.join(DATA, "specialtokensample.txt")
+    _run("--encode", "--input", src, "--model-path", model, "--output", enc)
+    import numpy as np
+    toks = np.fromfile(str(enc), dtype=np.uint32).tolist()
+    assert toks == [84, 104, 355, 32, 355, 306, 288, 101, 261, 101, 120, 116, 434, 287, 349, 262, 116, 97, 259, 115,
+                    32, 100258, 261, 119, 111, 306, 112, 310, 478, 108, 32, 100257, 348, 107, 290, 115, 46]
+    _run("--decode", "--input", enc, "--model-path", model, "--output", dec)
+    assert dec.read_bytes() == read_data("specialtokensample.txt")
+
+
+def mbpe_model_merges(blob):
+    """The merge lines of a .model file (the special-token lines before them come in hash-map order)."""
+    lines = blob.decode("utf-8").split("\n")
+    n_special = int(lines[2])
+    return lines[3 + n_special:]
+
+
+def test_cli_defaults_train_first_mode(tmp_path):
+    # `minbpe-cc --train -i x` with nothing else: gpt4 + first + vocab 512 (minbpe-cc.cpp:96-131)
+    model = tmp_path / "m"
+    _run("-t", "-i", os.path.join(DATA, "taylorswift.txt"), "-m", model)
+    assert model.read_bytes() == read_golden("taylorswift_gpt4_first_512.model")
+    # small.txt, basic, first: the loop ends after 7 merges (no pair left), SURVEY 8c
+    _run("-t", "-i", os.path.join(DATA, "small.txt"), "-m", model, "--encoder", "basic", "--vocab-size", 275)
+    assert mbpe_model_merges(model.read_bytes())[:-1] == ["98 99", "256 100", "257 101", "258 258", "97 259", "260 258", "261 10"]
 
 
 def test_tokenizer_train_binding():

@@ -1,0 +1,143 @@
+"""GPU tests at the sizes BASELINE.json's configs name, through the C-ABI:
+
+  config 3  bible stand-in (shakespeare.txt x 4), vocab 10,000: every merge and count
+            against the oracle, decode round trip, recount of the final stream against the pair table
+  config 4  SplitMix64 bytes to vocab 32,000 at 1 GiB: size-independent properties of the production
+            layout (dense pair table with 4 GiB of cells, batches of 512, fused passes, compactions);
+            and the first passes at 64 MiB with the same options against the oracle: merges, counts,
+            stream and the whole pair table
+  RCCL      the library's own communicator next to torch.distributed's (what bench.py does at N > 1)
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import mbpe
+import oracle as O
+from mbpe import check as C
+from conftest import ROOT, read_data
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    torch.cuda.set_device(0)
+    return torch.device("cuda", 0)
+
+
+def test_config3_bible_standin_vocab_10000(dev):
+    data = np.frombuffer(read_data("shakespeare.txt") * 4, dtype=np.uint8)
+    assert len(data) == 4461576
+    vocab = 10000
+    want_m, want_c = O.train(data, vocab)
+    with mbpe.Trainer(0) as tr:
+        m, c, st = tr.train_lexical(data, vocab)
+        assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+        corpus = torch.from_numpy(data.copy()).to(dev)
+        rt = C.decode_roundtrip(tr, m, corpus, torch, dev)
+        assert rt["ok"], rt
+        assert rt["n_live"] == st["n_live"]
+        recount = C.recount_pairs(tr, torch, dev)
+        table = {k: v for k, v in tr.pairs_dict().items() if v}
+        assert recount == table
+    assert C.counts_nonincreasing(c) and len(m) == vocab - 256
+    assert st["n_batches"] < len(m) // 4          # merges did share stream passes
+
+
+def test_config4_first_passes_against_oracle_64mib(dev):
+    """Production options (dense table sized for vocab 32,000, batches of up to 512, fused pass): the first
+    sequences on 64 MiB of the benchmark corpus, state compared with the oracle after them."""
+    n = 64 << 20
+    data = O.splitmix64_bytes(42, n)
+    with mbpe.Trainer(0) as tr:
+        tr.load_corpus(data)
+        tr.train_begin(32000)
+        done = 0
+        while done < 256:
+            got = tr.train_sequences(1)
+            assert got > 0
+            done += got
+        m, c = tr.train_result()
+        st = tr.stats()
+        assert len(m) == done and st["n_fused"] >= 1 and st["n_batches"] <= 8
+        ost = O.State(data)
+        want = []
+        for i in range(done):
+            top = ost.top()
+            want.append(top)
+            ost.merge(top[0], top[1], 256 + i)
+        assert m.tolist() == [[a, b] for a, b, _ in want]
+        assert c.tolist() == [cc for _, _, cc in want]
+        assert np.array_equal(tr.stream()[0], ost.stream()[0])
+        assert {k: v for k, v in tr.pairs_dict().items() if v} == {k: v for k, v in ost.table_dict().items() if v}
+        ost.close()
+
+
+def test_config4_full_vocab_properties_1gib(dev):
+    """1 GiB of the benchmark corpus to vocab 32,000 (what bench.py's full_run does at 4 GiB): chosen counts
+    never increase, decode(stream) == corpus, the incrementally maintained pair table equals a recount of the
+    final stream."""
+    from bench import splitmix64_device
+    n = 1 << 30
+    keep, corpus = splitmix64_device(42, n, dev)
+    torch.cuda.synchronize()
+    with mbpe.Trainer(0) as tr:
+        tr.load_corpus_device(corpus.data_ptr(), n, keep=keep)
+        tr.train_begin(32000)
+        assert tr.train_steps(32000 - 256) == 32000 - 256
+        m, c = tr.train_result()
+        st = tr.stats()
+        assert len(m) == 32000 - 256 and C.counts_nonincreasing(c)
+        assert st["n_fused"] >= 10 and st["n_compactions"] >= 1
+        rt = C.decode_roundtrip(tr, m, corpus, torch, dev)
+        assert rt["ok"], rt
+        assert rt["n_live"] == st["n_live"]
+        tm = C.dense_table_matches_recount(tr, torch, dev)
+        assert tm["ok"], tm
+    # the first merges are the oracle's on the whole-corpus byte-pair table
+    table = torch.zeros(65536, dtype=torch.int64, device=dev)
+    b64 = corpus.long()
+    table.scatter_add_(0, b64[:-1] * 256 + b64[1:], torch.ones(n - 1, dtype=torch.int64, device=dev))
+    first = int(torch.argmax(table))                 # ties: smallest key, like the trainer
+    assert (int(m[0][0]), int(m[0][1])) == (first >> 8, first & 0xFF) and int(c[0]) == int(table[first])
+
+
+def test_library_rccl_next_to_torch_distributed(dev):
+    """bench.py at N > 1 initialises torch.distributed's NCCL (= RCCL) backend first and the library's own
+    communicator (dlopen of librccl.so.1, ncclCommInitRank) second, in the same process.  Both must work
+    side by side; this is the 1-rank version of that sequence."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        x = torch.ones(1024, device=dev)
+        dist.all_reduce(x)                               # forces torch's communicator into existence
+        torch.cuda.synchronize()
+        uid = [mbpe.comm_unique_id()]
+        dist.broadcast_object_list(uid, src=0)
+        data = O.splitmix64_bytes(12, 200000)
+        want_m, want_c = O.train(data, 256 + 120)
+        with mbpe.Trainer(0) as t:
+            t.comm_init(uid[0], 0, 1)
+            t.set_option("force_exchange", 1)
+            t.load_corpus(data)
+            assert t.train_begin(256 + 120) == mbpe.OK
+            assert t.train_steps(120) == 120
+            m, c = t.train_result()
+        assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+        dist.all_reduce(x)                               # torch's communicator still works afterwards
+        torch.cuda.synchronize()
+        assert float(x[0]) == 1.0
+    finally:
+        if created:
+            dist.destroy_process_group()

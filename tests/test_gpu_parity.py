@@ -99,6 +99,76 @@ def test_train_golden_model_bytes(tr, name):
     assert stats["n_live"] == meta["final_len"] >= len(data) - int(counts.sum())
 
 
+FIRST_GOLDENS = sorted(k for k, v in INDEX.items() if v["mode"] == "first")
+
+
+@pytest.mark.parametrize("name", FIRST_GOLDENS)
+def test_train_first_mode_golden_model_bytes(tr, name):
+    # the reference CLI's default tie-break (PairCountInsertOrder), on the device
+    meta = INDEX[name]
+    data = _input(meta["input"])
+    enc = meta["encoder"]
+    off = None if enc == "basic" else mbpe.presplit(O.PATTERNS[enc], data)
+    merges, counts, stats = tr.train(data, meta["vocab"], off, conflict_resolution=0)
+    assert O.model_bytes(O.PATTERNS[enc], merges) == read_golden(name + ".model")
+    want_m, want_c = O.train(data, meta["vocab"], off, mode=O.FIRST)
+    assert counts.tolist() == want_c.tolist()
+
+
+def test_train_first_mode_kats(tr):
+    # small.txt @275: 7 merges, then no pair is left and the loop breaks (Tokenizer.h:586-588)
+    m, c, _ = tr.train(read_data("small.txt"), 275, conflict_resolution=0)
+    assert m.tolist() == [[98, 99], [256, 100], [257, 101], [258, 258], [97, 259], [260, 258], [261, 10]]
+    # test.cpp:136-186 "abcbcde": (98,99) -> 256, (97,256) -> 257, (257,256) -> 258
+    m, c, _ = tr.train(b"abcbcde", 259, conflict_resolution=0)
+    assert m.tolist() == [[98, 99], [97, 256], [257, 256]]
+    for data, vocab in ((b"", 300), (b"a", 300), (b"ab", 258), (b"aaaa", 262), (b"abababab", 260)):
+        want_m, want_c = O.train(data, vocab, mode=O.FIRST)
+        m, c, _ = tr.train(data, vocab, conflict_resolution=0)
+        assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_train_first_mode_fuzz(tr, seed):
+    """Tie-heavy inputs (small alphabets, low counts) against the oracle's rebuilt-table first mode: both
+    table layouts, chunked and not, holes and compactions in the stream."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(200, 30000))
+    data = rng.integers(97, 97 + int(rng.integers(2, 12)), size=n, dtype=np.uint8)
+    off = _random_chunks(rng, n, int(rng.integers(3, 40))) if seed % 2 else None
+    vocab = 256 + int(rng.integers(20, 400))
+    want_m, want_c = O.train(data, vocab, off, mode=O.FIRST)
+    tr.set_option("dense_table", seed % 3 != 0)
+    tr.set_option("compact_den", 40 if seed % 2 else 16)
+    try:
+        m, c, _ = tr.train(data, vocab, off, conflict_resolution=0)
+    finally:
+        tr.set_option("dense_table", -1)
+        tr.set_option("compact_den", 16)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
+def test_pair_count_rollback_paths(tr):
+    """The segment checksum of the pair-count scan: a pair repeated far beyond 65,535 times per workgroup
+    wraps a 16-bit counter, the segment is voided, restored from its snapshot and recounted; mixed with
+    stretches that pass, so snapshots with a non-zero residue are restored too."""
+    rng = np.random.default_rng(5)
+    n = 96 << 20
+    data = rng.integers(0, 256, size=n, dtype=np.uint8)
+    data[0] = 1
+    for lo in range(8 << 20, n, 24 << 20):          # 4 MiB stretches of one pair inside random bytes
+        data[lo:lo + (4 << 20)] = 97
+    tr.load_corpus(data)
+    assert np.array_equal(tr.pair_count_u8(), O.pair_count_u8(data))
+    off = _random_chunks(rng, n, 4096)
+    tr.load_corpus(data, off)
+    assert np.array_equal(tr.pair_count_u8(), O.pair_count_u8(data, off))
+    data = np.full(64 << 20, 7, dtype=np.uint8)      # every segment of every workgroup wraps
+    tr.load_corpus(data)
+    got = tr.pair_count_u8()
+    assert int(got[(7 << 8) | 7]) == len(data) - 1 and int(got.sum()) == len(data) - 1
+
+
 def test_train_kat_small_and_aaaa(tr):
     m, c, _ = tr.train_lexical(read_data("small.txt"), 275)
     want = [[98, 99], [100, 101], [256, 257], [258, 258], [97, 259], [258, 10], [260, 261]] + [[97, 98]] * 12

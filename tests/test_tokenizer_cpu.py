@@ -122,11 +122,16 @@ def test_encode_is_greedy_left_to_right_not_rank_ordered():
     assert tok.encode(b"").tolist() == [] and tok.encode(b"a").tolist() == [97]
 
 
-def test_first_mode_training_is_refused():
-    tok = mbpe.Tokenizer("")
-    with pytest.raises(mbpe.MbpeError) as e:
-        tok.train(b"abcabc", 300, conflict_resolution=mbpe.Tokenizer.FIRST)
-    assert "lexical" in str(e.value)
+def test_training_without_a_device_fails_loudly():
+    # no CPU fallback for either conflict resolution: here (no GPU) train must fail with NO_DEVICE
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    for cr in (mbpe.Tokenizer.FIRST, mbpe.Tokenizer.LEXICAL):
+        tok = mbpe.Tokenizer("")
+        with pytest.raises(mbpe.MbpeError) as e:
+            tok.train(b"abcabc", 300, conflict_resolution=cr)
+        assert "no usable HIP device" in str(e.value)
 
 
 def test_cli_argument_errors():

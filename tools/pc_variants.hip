@@ -115,14 +115,16 @@ __device__ __forceinline__ unsigned long long pc_checksum(const uint32_t *hist, 
 // SWEEP 0: none (exact only while no counter wraps)
 // SWEEP 2: none inside a segment of SEG iterations; at the segment end a checksum decides between
 //          flushing the segment and recounting it with sweeps (exact for any data)
-template <int THREADS, int SWEEP, int VPL>
+// FLUSH 0: global atomics per bin from every workgroup; 1: none (timing only); 2: dump the packed
+//          16-bit histogram to scratch[blockIdx] with plain stores, k_reduce sums the dumps
+template <int THREADS, int SWEEP, int VPL, int FLUSH = 0>
 __global__ __launch_bounds__(THREADS) void k_pc(const uint8_t *__restrict__ text, uint64_t n, uint32_t *__restrict__ bp,
-                                                uint32_t *__restrict__ n_redo) {
+                                                uint32_t *__restrict__ n_redo, uint32_t *__restrict__ scratch = nullptr) {
     __shared__ uint32_t hist[kPcWords];
     __shared__ unsigned long long red[THREADS / kWave];
     for (uint32_t w = threadIdx.x; w < (uint32_t)kPcWords; w += THREADS) hist[w] = 0;
     __syncthreads();
-    constexpr int EPOCH = 49152 / (THREADS * 16 * VPL);
+    constexpr int EPOCH = 49152 / (THREADS * 16 * VPL) > 0 ? 49152 / (THREADS * 16 * VPL) : 1;   // (VPL > 2: timing only)
     static_assert(EPOCH >= 1, "epoch");
     constexpr int ITER_VECS = THREADS * VPL;
 
@@ -221,7 +223,12 @@ __global__ __launch_bounds__(THREADS) void k_pc(const uint8_t *__restrict__ text
             if (seg_end == n_full && seg_end > seg) want -= 1;
             const unsigned long long got = pc_checksum<THREADS>(hist, red);
             if (got == want) {
-                pc_flush<THREADS>(hist, bp);
+                if (FLUSH == 0) pc_flush<THREADS>(hist, bp);
+                if (FLUSH == 2) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(scratch + (size_t)blockIdx.x * kPcWords);
+                    for (int k = 0; k < kPcWords / 4 / THREADS; ++k)
+                        dst[k * THREADS + threadIdx.x] = reinterpret_cast<uint4 *>(hist)[k * THREADS + threadIdx.x];
+                }
                 __syncthreads();
                 for (uint32_t w = threadIdx.x; w < (uint32_t)kPcWords; w += THREADS) hist[w] = 0;
                 __syncthreads();
@@ -267,9 +274,25 @@ struct Variant {
     void (*launch)(const uint8_t *, uint64_t, uint32_t *, uint32_t *, int);
 };
 
-template <int THREADS, int SWEEP, int VPL>
+uint32_t *g_scratch = nullptr;
+
+// sums the per-workgroup dumps: thread = one packed word (two bins)
+__global__ void k_reduce(const uint32_t *__restrict__ scratch, int n_wg, uint32_t *__restrict__ bp) {
+    const uint32_t word = blockIdx.x * blockDim.x + threadIdx.x;      // < 32768
+    uint32_t lo = 0, hi = 0;
+    for (int g = 0; g < n_wg; ++g) {
+        const uint32_t v = scratch[(size_t)g * kPcWords + word];
+        lo += v & 0xFFFFu;
+        hi += v >> 16;
+    }
+    if (lo) atomicAdd(&bp[pc_table_index(word)], lo);
+    if (hi) atomicAdd(&bp[pc_table_index(word | 0x8000u)], hi);
+}
+
+template <int THREADS, int SWEEP, int VPL, int FLUSH = 0>
 void launch(const uint8_t *text, uint64_t n, uint32_t *bp, uint32_t *redo, int cus) {
-    hipLaunchKernelGGL((k_pc<THREADS, SWEEP, VPL>), dim3(cus), dim3(THREADS), 0, 0, text, n, bp, redo);
+    hipLaunchKernelGGL((k_pc<THREADS, SWEEP, VPL, FLUSH>), dim3(cus), dim3(THREADS), 0, 0, text, n, bp, redo, g_scratch);
+    if (FLUSH == 2) hipLaunchKernelGGL(k_reduce, dim3(kPcWords / 256), dim3(256), 0, 0, g_scratch, cus, bp);
 }
 
 int main(int argc, char **argv) {
@@ -302,7 +325,13 @@ int main(int argc, char **argv) {
         {"512 thr, segment checksum, 2 vec/lane", launch<512, 2, 2>},
         {"512 thr, epoch sweeps, 2 vec/lane", launch<512, 1, 2>},
         {"1024 thr, NO sweeps, 2 vec", launch<1024, 0, 2>},
+        {"1024 thr, segment checksum, 3 vec/lane", launch<1024, 2, 3>},
+        {"1024 thr, segment checksum, 4 vec/lane", launch<1024, 2, 4>},
+        {"1024 thr, seg checksum, 2 vec, NO FLUSH (timing)", launch<1024, 2, 2, 1>},
+        {"1024 thr, seg checksum, 2 vec, dump + reduce", launch<1024, 2, 2, 2>},
+        {"1024 thr, seg checksum, 4 vec, dump + reduce", launch<1024, 2, 4, 2>},
     };
+    CHK(hipMalloc(&g_scratch, (size_t)cus * kPcWords * 4));
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));
     CHK(hipEventCreate(&e1));
