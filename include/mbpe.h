@@ -46,7 +46,7 @@ typedef enum {
     MBPE_ERR_STATE     = -5,  /* call order violated (e.g. steps before begin) */
     MBPE_ERR_OOM       = -6,  /* device or host allocation failed */
     MBPE_ERR_REGEX     = -7,  /* PCRE2 unavailable, compile or match error */
-    MBPE_ERR_SPLIT_GAP = -8,  /* split pattern left bytes unmatched */
+    MBPE_ERR_SPLIT_GAP = -8,  /* (unused since gaps between matches are skipped like the reference does) */
     MBPE_ERR_COMM      = -9,  /* RCCL unavailable or a collective failed */
     MBPE_ERR_OVERFLOW  = -10, /* pair table or count overflow detected on device */
     MBPE_ERR_IO        = -11  /* file could not be read / written */
@@ -122,6 +122,15 @@ MBPE_API void mbpe_destroy(mbpe_ctx *ctx);
 MBPE_API int mbpe_load_corpus(mbpe_ctx *ctx, const uint8_t *text, uint64_t n_bytes,
                               const uint64_t *chunk_off, uint64_t n_chunks,
                               int text_on_device);
+
+/* The same for chunks given as ranges [starts[c], ends[c]) (ascending, not overlapping) that need
+ * not tile the text: bytes outside every chunk are not part of the corpus, as in the reference's
+ * match loop (Tokenizer.h:506-540).  When there are such bytes the library trains on a packed copy
+ * of the chunks (host memory, or a device text that is copied back once); mbpe_stats.n_bytes is the
+ * packed size. */
+MBPE_API int mbpe_load_corpus_ranges(mbpe_ctx *ctx, const uint8_t *text, uint64_t n_bytes,
+                                     const uint64_t *starts, const uint64_t *ends, uint64_t n_chunks,
+                                     int text_on_device);
 
 /* The pair-count scan on the loaded byte corpus: calculate_freqs
  * (Tokenizer.h:127-146) with PairCountLexicalOrder::create_or_modify_pair
@@ -243,6 +252,26 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  */
 MBPE_API int mbpe_set_option(mbpe_ctx *ctx, const char *name, int64_t value);
 
+/* ---- encode on the device ----------------------------------------------- */
+
+/* internal_encode (Tokenizer.h:370-377) over all chunks of a text on HIP device `device_id`:
+ * every chunk is widened with text_to_vector (Tokenizer.h:85-100, including its rule that a chunk
+ * starting with NUL whose remainder parses with std::stoi is ONE token with that id -- how encode
+ * hands over special tokens, :635-637, :667-670) and run through internal_internal_encode
+ * (:325-367): left-to-right passes that replace ANY pair present in merges_lookup, until a pass
+ * replaces nothing.  The results are concatenated (:713-717).
+ *   text, chunk_off, n_chunks   as for mbpe_load_corpus (host memory; NULL chunk_off = one chunk)
+ *   merges                      2 * n_merges u32, merge k makes token 256 + k; a repeated pair keeps
+ *                               the last id (merges_lookup[pair] = idx, Tokenizer.h:579)
+ *   tokens_out                  may be NULL to query the count; cap = its capacity in tokens
+ *   n_passes_out                optional: stream passes made (the deepest chunk's passes)
+ * No CPU fallback: MBPE_ERR_NO_DEVICE without a HIP device.  Token ids must stay below 2^31 - 2. */
+MBPE_API int mbpe_encode_chunks(int device_id, const uint8_t *text, uint64_t n_bytes,
+                                const uint64_t *chunk_off, uint64_t n_chunks,
+                                const uint32_t *merges, uint32_t n_merges,
+                                uint32_t *tokens_out, uint64_t cap, uint64_t *n_out,
+                                uint32_t *n_passes_out);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---------------- */
 
 /* Rank 0 creates the id, every rank receives it out of band (the launcher
@@ -272,13 +301,19 @@ MBPE_API int mbpe_comm_exchange_done(mbpe_ctx *ctx);
 
 /* Regex pre-split, Tokenizer.h:500-540: successive non-empty PCRE2 matches
  * (options PCRE2_UTF|PCRE2_UCP, +PCRE2_CASELESS when the pattern contains
- * "(?i:", :407-415; PCRE2_NO_UTF_CHECK at match time, :512) become chunks.
- * Returns a handle holding n_chunks+1 offsets. */
+ * "(?i:", :407-415; PCRE2_NO_UTF_CHECK at match time, :512) become chunks
+ * [starts[c], ends[c]).  Bytes between matches belong to no chunk: the reference skips them
+ * (:506-540; the built-in gpt2/gpt4 patterns leave none on valid UTF-8).  When the chunks tile
+ * the text, mbpe_split_offsets gives the n_chunks + 1 offsets mbpe_load_corpus takes; otherwise it
+ * returns NULL and the chunks go to mbpe_load_corpus_ranges. */
 typedef struct mbpe_split mbpe_split;
 MBPE_API int  mbpe_presplit(const char *pattern, const uint8_t *text, uint64_t n_bytes,
                             mbpe_split **out);
 MBPE_API uint64_t        mbpe_split_count(const mbpe_split *s);
 MBPE_API const uint64_t *mbpe_split_offsets(const mbpe_split *s);
+MBPE_API int             mbpe_split_has_gaps(const mbpe_split *s);
+MBPE_API const uint64_t *mbpe_split_starts(const mbpe_split *s);
+MBPE_API const uint64_t *mbpe_split_ends(const mbpe_split *s);
 MBPE_API void            mbpe_split_free(mbpe_split *s);
 
 /* The split patterns of Tokenizer.h:59-60 ("gpt2", "gpt4"; "basic" = ""). */

@@ -48,6 +48,12 @@ MBPE_API int mbpe_tok_load(mbpe_tokenizer *t, const char *path, int verbose);
 MBPE_API int mbpe_tok_encode(mbpe_tokenizer *t, const uint8_t *text, uint64_t n, int verbose,
                              uint32_t *tokens_out, uint64_t cap, uint64_t *n_out);
 
+/* The same with internal_encode (Tokenizer.h:325-377) on HIP device `device_id`
+ * (mbpe_encode_chunks); special-token and regex splitting stay on the host.  No CPU
+ * fallback: MBPE_ERR_NO_DEVICE without a device. */
+MBPE_API int mbpe_tok_encode_device(mbpe_tokenizer *t, const uint8_t *text, uint64_t n, int verbose, int device_id,
+                                    uint32_t *tokens_out, uint64_t cap, uint64_t *n_out);
+
 /* decode, Tokenizer.h:725-751.  bytes_out may be NULL to query the length. */
 MBPE_API int mbpe_tok_decode(mbpe_tokenizer *t, const uint32_t *tokens, uint64_t n, int verbose,
                              uint8_t *bytes_out, uint64_t cap, uint64_t *n_out);

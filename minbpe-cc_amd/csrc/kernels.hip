@@ -289,7 +289,7 @@ constexpr uint32_t kPcHotBits = 0xE000u;   // counter >= 0x2000
 constexpr int kPcEpochIters = 3;           // slow loop: iterations of one vector per lane between sweeps
 constexpr int kPcVpl = 2;                  // fast loop: vectors per lane and iteration
 #ifndef MBPE_PC_SEG0
-#define MBPE_PC_SEG0 16
+#define MBPE_PC_SEG0 32
 #endif
 constexpr uint32_t kPcSeg0 = MBPE_PC_SEG0;  // first segment, in fast iterations of 32 Ki pairs
 constexpr uint32_t kPcSegMax = 4096;

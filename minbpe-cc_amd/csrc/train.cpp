@@ -518,6 +518,50 @@ int mbpe_load_corpus(mbpe_ctx *c, const uint8_t *text, uint64_t n_bytes, const u
     return MBPE_OK;
 }
 
+int mbpe_load_corpus_ranges(mbpe_ctx *c, const uint8_t *text, uint64_t n_bytes, const uint64_t *starts,
+                            const uint64_t *ends, uint64_t n_chunks, int text_on_device) {
+    if (!c || (!text && n_bytes) || ((!starts || !ends) && n_chunks)) {
+        mbpe_host::set_last_error("mbpe_load_corpus_ranges: NULL argument");
+        return MBPE_ERR_ARG;
+    }
+    uint64_t pos = 0, packed = 0;
+    bool tiled = true;
+    for (uint64_t i = 0; i < n_chunks; ++i) {
+        if (starts[i] < pos || ends[i] < starts[i] || ends[i] > n_bytes) {
+            mbpe_host::set_last_error("chunk ranges must be ascending, disjoint and inside the text");
+            return MBPE_ERR_ARG;
+        }
+        if (starts[i] != pos) tiled = false;
+        pos = ends[i];
+        packed += ends[i] - starts[i];
+    }
+    if (pos != n_bytes) tiled = false;
+    std::vector<uint64_t> off(n_chunks + 1);
+    if (tiled) {
+        for (uint64_t i = 0; i < n_chunks; ++i) off[i] = starts[i];
+        off[n_chunks] = n_bytes;
+        return mbpe_load_corpus(c, text, n_bytes, off.data(), n_chunks, text_on_device);
+    }
+    // bytes between the chunks are skipped (Tokenizer.h:506-540): train on the chunks packed together
+    std::vector<uint8_t> host_copy;
+    const uint8_t *src = text;
+    if (text_on_device) {
+        HIPCHK(hipSetDevice(c->device));
+        host_copy.resize(n_bytes);
+        HIPCHK(hipMemcpy(host_copy.data(), text, n_bytes, hipMemcpyDeviceToHost));
+        src = host_copy.data();
+    }
+    std::vector<uint8_t> buf(packed);
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n_chunks; ++i) {
+        off[i] = w;
+        memcpy(buf.data() + w, src + starts[i], ends[i] - starts[i]);
+        w += ends[i] - starts[i];
+    }
+    off[n_chunks] = w;
+    return mbpe_load_corpus(c, buf.data(), packed, off.data(), n_chunks, 0);
+}
+
 int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
     if (!c) return MBPE_ERR_ARG;
     if (!c->loaded) { mbpe_host::set_last_error("mbpe_pair_count_u8: no corpus loaded"); return MBPE_ERR_STATE; }

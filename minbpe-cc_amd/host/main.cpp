@@ -64,7 +64,8 @@ void usage() {
                  "  -v,--verbose                Print more things\n"
                  "  -c,--conflict-resolution TEXT:{first,lexical}\n"
                  "                              Conflict resolution strategy: 'first' or 'lexical'\n"
-                 "  --device INT                HIP device used for training (default 0)\n";
+                 "  --device INT                HIP device used for training (default 0)\n"
+                 "  --device-encode             When encoding, apply the merges on the HIP device (--device)\n";
 }
 
 }  // namespace
@@ -72,7 +73,7 @@ void usage() {
 int main(int argc, char *argv[]) {
     std::string input_path, output_path, special_token_path, encoder = "gpt4", model_path = "./output.model";
     std::string conflict_resolution_str = "first";
-    bool train = false, decode = false, encode = false, write_vocab = false, verbose = false;
+    bool train = false, decode = false, encode = false, write_vocab = false, verbose = false, device_encode = false;
     int vocab_size = 512, device = 0;
 
     // option parsing (the reference uses CLI11, :93-133)
@@ -110,6 +111,7 @@ int main(int argc, char *argv[]) {
         else if (arg == "-d" || arg == "--decode") decode = true;
         else if (arg == "-e" || arg == "--encode") encode = true;
         else if (arg == "-w" || arg == "--write-vocab") write_vocab = true;
+        else if (arg == "--device-encode") device_encode = true;
         else if (arg == "-v" || arg == "--verbose") verbose = true;
         else { std::cerr << "The following argument was not expected: " << arg << "\n"; return 109; }
     }
@@ -173,8 +175,11 @@ int main(int argc, char *argv[]) {
         if (load_file_to_string(input_path, &input, &err)) {
             std::vector<Token> encoded(input.size() + 1);
             uint64_t n = 0;
-            if (mbpe_tok_encode(rt, reinterpret_cast<const uint8_t *>(input.data()), input.size(), verbose,
-                                encoded.data(), encoded.size(), &n) != MBPE_OK) {
+            const uint8_t *in = reinterpret_cast<const uint8_t *>(input.data());
+            const int erc = device_encode
+                                ? mbpe_tok_encode_device(rt, in, input.size(), verbose, device, encoded.data(), encoded.size(), &n)
+                                : mbpe_tok_encode(rt, in, input.size(), verbose, encoded.data(), encoded.size(), &n);
+            if (erc != MBPE_OK) {
                 std::cerr << "Error: " << mbpe_last_error() << "\n";
                 rc = -1;
             } else {

@@ -295,7 +295,9 @@ const char *split_pattern_for(const std::string &encoder) {
 // ---- C-ABI ---------------------------------------------------------------
 
 struct mbpe_split {
-    std::vector<uint64_t> off;   // n_chunks + 1
+    std::vector<uint64_t> starts, ends;   // chunk c = [starts[c], ends[c])
+    std::vector<uint64_t> off;            // n_chunks + 1 offsets when the chunks tile the text, else empty
+    bool gaps = false;
 };
 
 extern "C" {
@@ -309,34 +311,39 @@ int mbpe_presplit(const char *pattern, const uint8_t *text, uint64_t n_bytes, mb
     mbpe_host::Splitter sp;
     int rc = sp.compile(pattern, &err);
     if (rc != MBPE_OK) { mbpe_host::set_last_error(err); return rc; }
-    std::vector<uint64_t> starts, ends;
-    rc = sp.split(text, n_bytes, &starts, &ends, &err);
-    if (rc != MBPE_OK) { mbpe_host::set_last_error(err); return rc; }
-    // The device layout wants contiguous chunks; the gpt2/gpt4 patterns match
-    // every byte of valid UTF-8 input, so a gap means an unsupported pattern.
-    uint64_t pos = 0;
-    for (size_t i = 0; i < starts.size(); i++) {
-        if (starts[i] != pos) {
-            mbpe_host::set_last_error("split pattern left bytes unmatched at offset " + std::to_string(pos));
-            return MBPE_ERR_SPLIT_GAP;
-        }
-        pos = ends[i];
-    }
-    if (pos != n_bytes) {
-        mbpe_host::set_last_error("split pattern left bytes unmatched at offset " + std::to_string(pos));
-        return MBPE_ERR_SPLIT_GAP;
-    }
     mbpe_split *s = new mbpe_split();
-    const bool none = starts.empty();
-    s->off.swap(starts);              // chunk c starts where chunk c - 1 ended (checked above)
-    s->off.push_back(n_bytes);
-    if (none) { s->off.clear(); s->off.push_back(0); }
+    rc = sp.split(text, n_bytes, &s->starts, &s->ends, &err);
+    if (rc != MBPE_OK) { mbpe_host::set_last_error(err); delete s; return rc; }
+    // The gpt2/gpt4 patterns match every byte of valid UTF-8 input; any other pattern may leave
+    // bytes between matches, which the reference simply skips (Tokenizer.h:506-540).
+    uint64_t pos = 0;
+    for (size_t i = 0; i < s->starts.size(); i++) {
+        if (s->starts[i] != pos) s->gaps = true;
+        pos = s->ends[i];
+    }
+    if (pos != n_bytes) s->gaps = true;
+    if (!s->gaps) {
+        s->off = s->starts;           // chunk c starts where chunk c - 1 ended
+        s->off.push_back(n_bytes);
+        if (s->starts.empty()) { s->off.clear(); s->off.push_back(0); }
+    }
     *out = s;
     return MBPE_OK;
 }
 
-uint64_t mbpe_split_count(const mbpe_split *s) { return s ? s->off.size() - 1 : 0; }
-const uint64_t *mbpe_split_offsets(const mbpe_split *s) { return s ? s->off.data() : nullptr; }
+uint64_t mbpe_split_count(const mbpe_split *s) { return s ? s->starts.size() : 0; }
+const uint64_t *mbpe_split_offsets(const mbpe_split *s) {
+    if (!s) return nullptr;
+    if (s->gaps) {
+        mbpe_host::set_last_error("the split pattern left bytes unmatched: use mbpe_split_starts / mbpe_split_ends "
+                                  "with mbpe_load_corpus_ranges");
+        return nullptr;
+    }
+    return s->off.data();
+}
+int mbpe_split_has_gaps(const mbpe_split *s) { return s && s->gaps ? 1 : 0; }
+const uint64_t *mbpe_split_starts(const mbpe_split *s) { return s ? s->starts.data() : nullptr; }
+const uint64_t *mbpe_split_ends(const mbpe_split *s) { return s ? s->ends.data() : nullptr; }
 void mbpe_split_free(mbpe_split *s) { delete s; }
 
 const char *mbpe_split_pattern(const char *encoder_name) {

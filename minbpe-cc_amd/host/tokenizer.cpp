@@ -8,6 +8,7 @@
 #include "mbpe_tokenizer.h"
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -86,22 +87,12 @@ void Tokenizer::train(const std::string &text, int vocab_size, CONFLICT_RESOLUTI
     merges_lookup_.clear();
     initialize_vocab();
 
-    std::vector<uint64_t> starts, ends, off;
+    std::vector<uint64_t> starts, ends;
     std::string err;
     const uint8_t *bytes = reinterpret_cast<const uint8_t *>(text.data());
     if (splitter_.split(bytes, text.size(), &starts, &ends, &err) != MBPE_OK) throw std::runtime_error(err);
     if (verbose) std::cout << "Split input text into " << starts.size() << " chunks\n";   // :546-548
     const bool chunked = splitter_.has_pattern();
-    if (chunked) {
-        uint64_t pos = 0;
-        for (size_t i = 0; i < starts.size(); ++i) {
-            if (starts[i] != pos) throw std::runtime_error("split pattern left bytes unmatched");
-            off.push_back(pos);
-            pos = ends[i];
-        }
-        if (pos != text.size()) throw std::runtime_error("split pattern left bytes unmatched");
-        off.push_back(text.size());
-    }
 
     mbpe_ctx *ctx = nullptr;
     if (mbpe_create(device, &ctx) != MBPE_OK) throw std::runtime_error(mbpe_last_error());
@@ -110,9 +101,14 @@ void Tokenizer::train(const std::string &text, int vocab_size, CONFLICT_RESOLUTI
     std::vector<int32_t> had(cap + 1);
     uint32_t n_merges = 0;
     mbpe_stats st;
-    int rc = mbpe_train(ctx, bytes, text.size(), chunked ? off.data() : nullptr, chunked ? off.size() - 1 : 0,
-                        static_cast<uint32_t>(vocab_size), conflict_resolution == LEXICAL ? 1 : 0, flat.data(),
-                        had.data(), &n_merges, &st);
+    // chunks as ranges: bytes between two matches belong to no chunk, as in the reference's loop (:506-540)
+    int rc = chunked ? mbpe_load_corpus_ranges(ctx, bytes, text.size(), starts.data(), ends.data(), starts.size(), 0)
+                     : mbpe_load_corpus(ctx, bytes, text.size(), nullptr, 0, 0);
+    if (rc == MBPE_OK) rc = mbpe_set_option(ctx, "conflict_resolution", conflict_resolution == LEXICAL ? 1 : 0);
+    if (rc == MBPE_OK) rc = mbpe_train_begin(ctx, static_cast<uint32_t>(vocab_size));
+    if (rc == MBPE_OK) rc = mbpe_train_steps(ctx, cap, nullptr);
+    if (rc == MBPE_OK) rc = mbpe_train_result(ctx, flat.data(), had.data(), cap, &n_merges);
+    if (rc == MBPE_OK) rc = mbpe_get_stats(ctx, &st);
     std::string msg = rc == MBPE_OK ? "" : mbpe_last_error();
     mbpe_destroy(ctx);
     if (rc != MBPE_OK) throw std::runtime_error(msg);
@@ -137,31 +133,29 @@ void Tokenizer::train(const std::string &text, int vocab_size, CONFLICT_RESOLUTI
 }
 
 // :605-650
+// :605-650.  Same result as the reference's rescan-from-the-cursor loop, computed in one sweep: every occurrence of
+// every special token is listed once, sorted by (position, token order), and an occurrence is taken when it starts
+// at or after the end of the previous one taken.  A taken token becomes the marker "\0<id>" (:635-637).
 std::vector<std::string> Tokenizer::split_on_special(const std::string &text) const {
-    std::vector<std::string> result;
-    if (special_tokens_.empty()) { result.push_back(text); return result; }
-    size_t pos = 0, last = 0;
-    while (pos < text.size()) {
-        size_t found_pos = std::string::npos;
-        std::string found_token;
-        Token found_id = 0;
-        for (const auto &kv : special_tokens_) {
-            size_t p = text.find(kv.first, pos);
-            if (p != std::string::npos && (found_pos == std::string::npos || p < found_pos)) {
-                found_pos = p; found_token = kv.first; found_id = kv.second;
-            }
-        }
-        if (found_pos == std::string::npos) break;
-        if (found_pos > last) result.push_back(text.substr(last, found_pos - last));
-        std::string marker(1, '\0');
-        marker += std::to_string(found_id);
-        result.push_back(marker);
-        pos = found_pos + found_token.size();
-        last = pos;
+    std::vector<std::string> parts;
+    struct Occ { size_t pos; size_t tok; };
+    std::vector<Occ> occ;
+    for (size_t k = 0; k < special_tokens_.size(); ++k) {
+        const std::string &name = special_tokens_[k].first;
+        if (name.empty()) continue;
+        for (size_t p = text.find(name); p != std::string::npos; p = text.find(name, p + 1)) occ.push_back({p, k});
     }
-    if (last < text.size()) result.push_back(text.substr(last));
-    if (result.empty()) result.push_back(text);
-    return result;
+    std::sort(occ.begin(), occ.end(), [](const Occ &a, const Occ &b) { return a.pos != b.pos ? a.pos < b.pos : a.tok < b.tok; });
+    size_t cursor = 0;
+    for (const Occ &o : occ) {
+        if (o.pos < cursor) continue;                      // inside a token already taken
+        if (o.pos > cursor) parts.push_back(text.substr(cursor, o.pos - cursor));
+        parts.push_back(std::string(1, '\0') + std::to_string(special_tokens_[o.tok].second));
+        cursor = o.pos + special_tokens_[o.tok].first.size();
+    }
+    if (cursor < text.size()) parts.push_back(text.substr(cursor));
+    if (parts.empty()) parts.push_back(text);
+    return parts;
 }
 
 // :325-367: one left-to-right pass replacing ANY pair found in merges_lookup
@@ -191,8 +185,8 @@ std::vector<Token> Tokenizer::internal_internal_encode(std::vector<Token> text) 
     }
 }
 
-// :653-722
-std::vector<Token> Tokenizer::encode(const std::string &text, bool verbose) {
+// :653-722.  device < 0: internal_encode on the host (below); device >= 0: on that HIP device (mbpe_encode_chunks)
+std::vector<Token> Tokenizer::encode(const std::string &text, bool verbose, int device) {
     auto split_text = split_on_special(text);
     if (verbose) {
         std::cout << "Splitting input text into " << split_text.size() << " parts\n";
@@ -201,28 +195,44 @@ std::vector<Token> Tokenizer::encode(const std::string &text, bool verbose) {
             std::cout << "Part: \"" << part << "\" special: " << is_special << "\n";
         }
     }
-    std::vector<std::vector<Token>> text_chunks;
+    // the chunks, as one byte buffer + offsets: special markers and, with a pattern, the regex matches of every
+    // other part (:664-704); without one, every part is a chunk (:706-709)
+    std::string buf;
+    std::vector<uint64_t> off{0};
+    buf.reserve(text.size() + 16 * split_text.size());
     for (const auto &part : split_text) {
-        if (splitter_.has_pattern()) {
-            if (part.size() > 0 && part[0] == '\0') {           // special token marker, :667-671
-                text_chunks.push_back(text_to_vector(part.data(), part.size()));
-                continue;
-            }
+        if (splitter_.has_pattern() && !(part.size() > 0 && part[0] == '\0')) {
             std::vector<uint64_t> starts, ends;
             std::string err;
             if (splitter_.split(reinterpret_cast<const uint8_t *>(part.data()), part.size(), &starts, &ends, &err) !=
                 MBPE_OK)
                 throw std::runtime_error(err);                   // :686-691
-            for (size_t i = 0; i < starts.size(); ++i)
-                text_chunks.push_back(text_to_vector(part.data() + starts[i], ends[i] - starts[i]));
+            for (size_t i = 0; i < starts.size(); ++i) {
+                buf.append(part, starts[i], ends[i] - starts[i]);
+                off.push_back(buf.size());
+            }
         } else {
-            text_chunks.push_back(text_to_vector(part.data(), part.size()));   // :706-709
+            buf += part;
+            off.push_back(buf.size());
         }
     }
     std::vector<Token> out;
-    for (auto &chunk : text_chunks) {                           // internal_encode :370-377 + flatten :713-717
-        auto enc = internal_internal_encode(std::move(chunk));
-        out.insert(out.end(), enc.begin(), enc.end());
+    if (device >= 0) {
+        std::vector<uint32_t> flat;
+        flat.reserve(2 * merges_.size());
+        for (const auto &m : merges_) { flat.push_back(m.first); flat.push_back(m.second); }
+        out.resize(buf.size());
+        uint64_t n = 0;
+        const int rc = mbpe_encode_chunks(device, reinterpret_cast<const uint8_t *>(buf.data()), buf.size(), off.data(),
+                                          off.size() - 1, flat.data(), static_cast<uint32_t>(merges_.size()),
+                                          out.data(), out.size(), &n, nullptr);
+        if (rc != MBPE_OK) throw std::runtime_error(mbpe_last_error());
+        out.resize(n);
+    } else {
+        for (size_t c = 0; c + 1 < off.size(); ++c) {           // internal_encode :370-377 + flatten :713-717
+            auto enc = internal_internal_encode(text_to_vector(buf.data() + off[c], off[c + 1] - off[c]));
+            out.insert(out.end(), enc.begin(), enc.end());
+        }
     }
     if (verbose) std::cout << "Encoded input text (length " << text.length() << ") to " << out.size() << " tokens\n";
     return out;
@@ -422,6 +432,23 @@ int mbpe_tok_encode(mbpe_tokenizer *t, const uint8_t *text, uint64_t n, int verb
         memcpy(tokens_out, enc.data(), enc.size() * sizeof(uint32_t));
         return (int)MBPE_OK;
     });
+}
+
+int mbpe_tok_encode_device(mbpe_tokenizer *t, const uint8_t *text, uint64_t n, int verbose, int device_id,
+                           uint32_t *tokens_out, uint64_t cap, uint64_t *n_out) {
+    if (!t || (!text && n) || !n_out || device_id < 0) return MBPE_ERR_ARG;
+    try {
+        auto enc = t->t->encode(std::string(reinterpret_cast<const char *>(text), n), verbose != 0, device_id);
+        *n_out = enc.size();
+        if (!tokens_out) return MBPE_OK;
+        if (cap < enc.size()) { mbpe_host::set_last_error("tokens_out too small"); return MBPE_ERR_ARG; }
+        memcpy(tokens_out, enc.data(), enc.size() * sizeof(uint32_t));
+        return MBPE_OK;
+    } catch (const std::exception &e) {
+        const std::string msg = e.what();
+        mbpe_host::set_last_error(msg);
+        return msg.find("no usable HIP device") != std::string::npos ? MBPE_ERR_NO_DEVICE : MBPE_ERR_ARG;
+    }
 }
 
 int mbpe_tok_decode(mbpe_tokenizer *t, const uint32_t *tokens, uint64_t n, int verbose, uint8_t *bytes_out,

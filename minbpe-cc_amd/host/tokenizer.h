@@ -31,7 +31,8 @@ public:
     // :489-598; both CONFLICT_RESOLUTION values run on HIP device `device` (mbpe_train)
     void train(const std::string &text, int vocab_size, CONFLICT_RESOLUTION conflict_resolution, bool verbose,
                int device = 0);
-    std::vector<Token> encode(const std::string &text, bool verbose);      // :653-722
+    // :653-722; device >= 0 runs internal_encode (:325-377) on that HIP device instead of the host
+    std::vector<Token> encode(const std::string &text, bool verbose, int device = -1);
     std::string decode(const std::vector<Token> &tokens, bool verbose);    // :725-751
     bool load(const std::string &path, bool verbose);                      // :754-872
     bool save(const std::string &path, bool write_vocab);                  // :875-926

@@ -25,12 +25,14 @@ EXPORTS = [
     "mbpe_train_lexical", "mbpe_train", "mbpe_get_stats", "mbpe_get_stream", "mbpe_stream_device", "mbpe_table_device", "mbpe_get_pairs", "mbpe_compact",
     "mbpe_set_option", "mbpe_comm_unique_id", "mbpe_comm_init", "mbpe_comm_init_external",
     "mbpe_comm_exchange_buffer", "mbpe_comm_exchange_done", "mbpe_presplit",
-    "mbpe_split_count", "mbpe_split_offsets", "mbpe_split_free", "mbpe_split_pattern",
+    "mbpe_split_count", "mbpe_split_offsets", "mbpe_split_has_gaps", "mbpe_split_starts", "mbpe_split_ends",
+    "mbpe_split_free", "mbpe_load_corpus_ranges", "mbpe_split_pattern", "mbpe_encode_chunks",
 ]
 # include/mbpe_tokenizer.h
 TOK_EXPORTS = [
     "mbpe_tok_create", "mbpe_tok_destroy", "mbpe_tok_set_special_tokens", "mbpe_tok_train", "mbpe_tok_set_merges",
-    "mbpe_tok_get_merges", "mbpe_tok_save", "mbpe_tok_load", "mbpe_tok_encode", "mbpe_tok_decode",
+    "mbpe_tok_get_merges", "mbpe_tok_save", "mbpe_tok_load", "mbpe_tok_encode", "mbpe_tok_encode_device",
+    "mbpe_tok_decode",
 ]
 
 
@@ -104,10 +106,17 @@ def lib():
     L.mbpe_split_count.restype = u64
     L.mbpe_split_offsets.argtypes = [vp]
     L.mbpe_split_offsets.restype = ctypes.POINTER(ctypes.c_uint64)
+    L.mbpe_split_has_gaps.argtypes = [vp]
+    L.mbpe_split_starts.argtypes = [vp]
+    L.mbpe_split_starts.restype = ctypes.POINTER(ctypes.c_uint64)
+    L.mbpe_split_ends.argtypes = [vp]
+    L.mbpe_split_ends.restype = ctypes.POINTER(ctypes.c_uint64)
+    L.mbpe_load_corpus_ranges.argtypes = [vp, vp, u64, vp, vp, u64, i32]
     L.mbpe_split_free.argtypes = [vp]
     L.mbpe_split_free.restype = None
     L.mbpe_split_pattern.argtypes = [ctypes.c_char_p]
     L.mbpe_split_pattern.restype = ctypes.c_char_p
+    L.mbpe_encode_chunks.argtypes = [i32, vp, u64, vp, u64, vp, u32, vp, u64, vp, vp]
     L.mbpe_tok_create.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
     L.mbpe_tok_destroy.argtypes = [vp]
     L.mbpe_tok_destroy.restype = None
@@ -118,6 +127,7 @@ def lib():
     L.mbpe_tok_save.argtypes = [vp, ctypes.c_char_p, i32]
     L.mbpe_tok_load.argtypes = [vp, ctypes.c_char_p, i32]
     L.mbpe_tok_encode.argtypes = [vp, vp, u64, i32, vp, u64, vp]
+    L.mbpe_tok_encode_device.argtypes = [vp, vp, u64, i32, i32, vp, u64, vp]
     L.mbpe_tok_decode.argtypes = [vp, vp, u64, i32, vp, u64, vp]
     _lib = L
     return L
@@ -142,6 +152,22 @@ def split_pattern(encoder):
     return p.decode("utf-8")
 
 
+def presplit_ranges(pattern, data):
+    """The same as (starts, ends) arrays: chunks need not tile the text (bytes between matches are skipped)."""
+    text = _u8(data)
+    h = ctypes.c_void_p()
+    _check(lib().mbpe_presplit(pattern.encode("utf-8"), text.ctypes.data if len(text) else None,
+                               len(text), ctypes.byref(h)))
+    try:
+        n = lib().mbpe_split_count(h)
+        if n == 0:
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+        return (np.ctypeslib.as_array(lib().mbpe_split_starts(h), shape=(n,)).copy(),
+                np.ctypeslib.as_array(lib().mbpe_split_ends(h), shape=(n,)).copy())
+    finally:
+        lib().mbpe_split_free(h)
+
+
 def presplit(pattern, data):
     """Tokenizer::train's regex pre-split (Tokenizer.h:500-540) -> uint64 offsets [n_chunks+1]."""
     text = _u8(data)
@@ -150,9 +176,26 @@ def presplit(pattern, data):
                                len(text), ctypes.byref(h)))
     try:
         n = lib().mbpe_split_count(h)
-        return np.ctypeslib.as_array(lib().mbpe_split_offsets(h), shape=(n + 1,)).copy()
+        p = lib().mbpe_split_offsets(h)
+        if not p:
+            raise MbpeError(ERR_SPLIT_GAP, lib().mbpe_last_error().decode("utf-8", "replace"))
+        return np.ctypeslib.as_array(p, shape=(n + 1,)).copy()
     finally:
         lib().mbpe_split_free(h)
+
+
+def encode_chunks(data, chunk_off, merges, device=0):
+    """internal_encode on the device (mbpe_encode_chunks) -> (uint32 tokens, passes)."""
+    text = _u8(data)
+    off = None if chunk_off is None else np.ascontiguousarray(chunk_off, dtype=np.uint64)
+    m = np.ascontiguousarray(merges, dtype=np.uint32).reshape(-1, 2)
+    n, passes = ctypes.c_uint64(), ctypes.c_uint32()
+    out = np.zeros(max(len(text), 1), dtype=np.uint32)
+    _check(lib().mbpe_encode_chunks(device, text.ctypes.data if len(text) else None, len(text),
+                                    None if off is None else off.ctypes.data, 0 if off is None else len(off) - 1,
+                                    m.ctypes.data if len(m) else None, len(m), out.ctypes.data, len(out),
+                                    ctypes.byref(n), ctypes.byref(passes)))
+    return out[:n.value].copy(), passes.value
 
 
 class Trainer:
@@ -191,6 +234,15 @@ class Trainer:
         _check(lib().mbpe_load_corpus(self._h, text.ctypes.data if len(text) else None, len(text),
                                       None if off is None else off.ctypes.data,
                                       0 if off is None else len(off) - 1, 0))
+
+    def load_corpus_ranges(self, data, starts, ends):
+        text = _u8(data)
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        en = np.ascontiguousarray(ends, dtype=np.uint64)
+        self._keep = (text, st, en)
+        _check(lib().mbpe_load_corpus_ranges(self._h, text.ctypes.data if len(text) else None, len(text),
+                                             st.ctypes.data if len(st) else None, en.ctypes.data if len(en) else None,
+                                             len(st), 0))
 
     def load_corpus_device(self, dev_ptr, n_bytes, chunk_off=None, keep=None):
         """dev_ptr: device address of n_bytes corpus bytes (e.g. torch tensor .data_ptr())."""
@@ -365,12 +417,17 @@ class Tokenizer:
     def load(self, path, verbose=False):
         _check(lib().mbpe_tok_load(self._h, os.fsencode(path), int(verbose)))
 
-    def encode(self, data):
+    def encode(self, data, device=None):
+        """device None: internal_encode on the host; an int: on that HIP device (mbpe_tok_encode_device)."""
         text = _u8(data)
         n = ctypes.c_uint64()
         out = np.zeros(max(len(text), 1), dtype=np.uint32)
-        _check(lib().mbpe_tok_encode(self._h, text.ctypes.data if len(text) else None, len(text), 0,
-                                     out.ctypes.data, len(out), ctypes.byref(n)))
+        if device is None:
+            _check(lib().mbpe_tok_encode(self._h, text.ctypes.data if len(text) else None, len(text), 0,
+                                         out.ctypes.data, len(out), ctypes.byref(n)))
+        else:
+            _check(lib().mbpe_tok_encode_device(self._h, text.ctypes.data if len(text) else None, len(text), 0, device,
+                                                out.ctypes.data, len(out), ctypes.byref(n)))
         return out[:n.value].copy()
 
     def decode(self, tokens):

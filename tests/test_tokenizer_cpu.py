@@ -122,6 +122,57 @@ def test_encode_is_greedy_left_to_right_not_rank_ordered():
     assert tok.encode(b"").tolist() == [] and tok.encode(b"a").tolist() == [97]
 
 
+def _reference_split_on_special(text, specials):
+    """Tokenizer.h:605-650 as written: rescan from the cursor for the earliest occurrence of any special token."""
+    if not specials:
+        return [text]
+    result, pos, last = [], 0, 0
+    while pos < len(text):
+        found_pos, found = -1, None
+        for name, tid in specials:
+            p = text.find(name, pos)
+            if p != -1 and (found_pos == -1 or p < found_pos):
+                found_pos, found = p, (name, tid)
+        if found_pos == -1:
+            break
+        if found_pos > last:
+            result.append(text[last:found_pos])
+        result.append(b"\x00" + str(found[1]).encode())
+        pos = last = found_pos + len(found[0])
+    if last < len(text):
+        result.append(text[last:])
+    return result or [text]
+
+
+def test_split_on_special_equals_the_reference_loop():
+    specials = [(b"<|a|>", 1000), (b"<|ab|>", 1001), (b"|><|", 1002), (b"<<", 1003)]
+    tok = mbpe.Tokenizer("")
+    tok.set_special_tokens_from_file(b"".join(n + b" " + str(i).encode() + b"\n" for n, i in specials))
+    tok.set_merges(np.zeros((0, 2), dtype=np.uint32))
+    rng = np.random.default_rng(3)
+    pieces = [b"<|a|>", b"<|ab|>", b"|><|", b"<<", b"<", b"|", b">", b"a", b"b", b"xyz", b" "]
+    for _ in range(300):
+        text = b"".join(pieces[int(i)] for i in rng.integers(0, len(pieces), size=int(rng.integers(0, 30))))
+        want = []
+        for part in _reference_split_on_special(text, specials):
+            if part[:1] == b"\x00":
+                want.append(int(part[1:]))
+            else:
+                want.extend(part)
+        assert tok.encode(text).tolist() == want, text
+
+
+def test_presplit_ranges_with_gaps():
+    data = b"ab, cd! e"
+    starts, ends = mbpe.presplit_ranges(r"\p{L}+", data)
+    assert starts.tolist() == [0, 4, 8] and ends.tolist() == [2, 6, 9]
+    with pytest.raises(mbpe.MbpeError):
+        mbpe.presplit(r"\p{L}+", data)
+    off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data)
+    starts, ends = mbpe.presplit_ranges(O.GPT4_SPLIT_PATTERN, data)
+    assert off[:-1].tolist() == starts.tolist() and off[1:].tolist() == ends.tolist()
+
+
 def test_training_without_a_device_fails_loudly():
     # no CPU fallback for either conflict resolution: here (no GPU) train must fail with NO_DEVICE
     import torch
@@ -132,6 +183,11 @@ def test_training_without_a_device_fails_loudly():
         with pytest.raises(mbpe.MbpeError) as e:
             tok.train(b"abcabc", 300, conflict_resolution=cr)
         assert "no usable HIP device" in str(e.value)
+    tok = mbpe.Tokenizer("")
+    tok.set_merges(np.array([[97, 98]], dtype=np.uint32))
+    with pytest.raises(mbpe.MbpeError) as e:
+        tok.encode(b"abab", device=0)
+    assert e.value.code == mbpe.ERR_NO_DEVICE
 
 
 def test_cli_argument_errors():
