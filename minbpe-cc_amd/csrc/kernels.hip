@@ -498,7 +498,8 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__r
                 ck = pc_check(hist, 0, red);
             }
             resid = ck.sum;
-            if (ck.max < 0x1000u && seg_iters < kPcSegMax) seg_iters *= 2;
+            if (ck.max < 0x0800u && seg_iters * 4 <= kPcSegMax) seg_iters *= 4;
+            else if (ck.max < 0x1000u && seg_iters * 2 <= kPcSegMax) seg_iters *= 2;
             else if (ck.max >= 0x8000u && seg_iters > 4) seg_iters /= 2;
         } else {
             // a counter wrapped: the segment is void.  Restore and recount it with sweeps
@@ -2225,6 +2226,37 @@ __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &
     }
 }
 
+// Can tt_rename change anything in this tile?  It renames tokens at ODD positions of runs of a (t,t) member's
+// token, and a token at an odd position equals the live token before it.  So unless some live token of the
+// tile (or of its halo) has the same id as its predecessor AND that id is a member's token, the tile is left
+// alone -- which is nearly always: two per tile of random bytes repeat their predecessor, one in sixteen of
+// those is one of the batch's handful of (t,t) tokens.  Conservative (chunk ends are ignored).
+// nxt[j]: the live token after slot j (kHole: none); tile_first: the tile's first live token.
+template <bool CHUNKED>
+__device__ __forceinline__ bool tt_needed(const uint32_t s[8], const uint32_t nxt[8], const Halo &h,
+                                          uint32_t tile_first, const TTInfo &ti) {
+    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    auto member = [&](uint32_t v) -> bool {
+        const uint32_t id = v & idmask;
+        return (ti.map[id & (kTTSlots - 1u)] & 0xFFFFu) == id;
+    };
+    uint32_t eqm = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) eqm |= (((s[j] ^ nxt[j]) & idmask) == 0u ? 1u : 0u) << j;     // (a hole has no token's id)
+    bool need = false;
+    if (__ballot(eqm != 0u) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if ((eqm >> j) & 1u) need = need || member(s[j]);
+    }
+    // halo (uniform): p1 before the tile's first token, p2 before p1, n2 after n1
+    bool hneed = false;
+    if (h.p1 != kHole && (((h.p1 ^ tile_first) & idmask) == 0u || (h.p2 != kHole && ((h.p2 ^ h.p1) & idmask) == 0u)))
+        hneed = member(h.p1);
+    if (h.n1 != kHole && h.n2 != kHole && ((h.n1 ^ h.n2) & idmask) == 0u) hneed = hneed || member(h.n1);
+    return __ballot(need) != 0ull || hneed;
+}
+
 // exact neighbours of every slot, two deep on both sides (shared by the scan
 // and rewrite passes of a batch)
 struct Neigh {
@@ -2628,7 +2660,9 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
 
         uint4 outq = t0.q;
         const uint32_t old_x = rlane(t0.smw, 4), old_y = rlane(t0.smw, 5), old_z = rlane(t0.smw, 6);
-        if ((old_z & 0xFFFFu) != 0) {
+        if (DIAG == 4) {                 // timing-only build: copy
+            asm volatile("" :: "v"(t0.smw));
+        } else if ((old_z & 0xFFFFu) != 0) {
             uint32_t s[8];
             unpack8(t0.q, s);
             Halo h;
@@ -2641,32 +2675,42 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             } else {
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
-            if (TT) tt_rename<CHUNKED>(s, h, ti, run_in[tile]);
-            uint32_t lf = kHole;
+            uint32_t lf, c_init, tile_first, cj[8];
+            unsigned long long m_live;
+            // (t,t) members: the renaming changes the tile's tokens, so everything derived from them is redone
+            // after it -- for the few tiles that need it (tt_needed)
+            for (int rep = 0;; ++rep) {
+                lf = kHole;
 #pragma unroll
-            for (int j = 7; j >= 0; --j) lf = s[j] != kHole ? s[j] : lf;
-            const unsigned long long m_live = __ballot(lf != kHole);
-            uint32_t c_init;
-            if (m_live == ~0ull) {               // every lane holds a live token (nearly always): the next lane's
-                c_init = wave_from_next(lf, h.n1);
-            } else {
-                const unsigned long long hi = m_live & gt_mask;
-                const uint32_t nf = __shfl(lf, hi ? (uint32_t)__builtin_ctzll(hi) : lane, kWave);
-                c_init = hi ? nf : h.n1;
+                for (int j = 7; j >= 0; --j) lf = s[j] != kHole ? s[j] : lf;
+                m_live = __ballot(lf != kHole);
+                if (m_live == ~0ull) {               // every lane holds a live token (nearly always): the next lane's
+                    c_init = wave_from_next(lf, h.n1);
+                } else {
+                    const unsigned long long hi = m_live & gt_mask;
+                    const uint32_t nf = __shfl(lf, hi ? (uint32_t)__builtin_ctzll(hi) : lane, kWave);
+                    c_init = hi ? nf : h.n1;
+                }
+                tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
+                uint32_t c = c_init;
+#pragma unroll
+                for (int j = 7; j >= 0; --j) {
+                    cj[j] = c;
+                    c = s[j] != kHole ? s[j] : c;
+                }
+                if (!TT || rep || DIAG == 5 || !tt_needed<CHUNKED>(s, cj, h, tile_first, ti)) break;
+                tt_rename<CHUNKED>(s, h, ti, run_in[tile]);
             }
-            uint32_t c = c_init;
-            uint32_t cj[8];
             uint32_t Am = 0;             // bit j: slot j starts a match
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                cj[j] = c;
-                const bool hit = pair_hit(lut, s[j], CHUNKED ? c & idmask : c);     // (ids are 16-bit: no mask needed)
+                const bool hit = pair_hit(lut, s[j], CHUNKED ? cj[j] & idmask : cj[j]);     // (ids are 16-bit: no mask needed)
                 Am = Am + Am + (hit ? 1u : 0u);         // one add-with-carry, the carry being the compare mask
-                c = s[j] != kHole ? s[j] : c;
             }
             const bool any = Am != 0u;
-            const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
-            if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
+            if (DIAG == 3 || DIAG == 5) {    // timing-only build: membership tests, no merge
+                asm volatile("" :: "v"(Am));
+            } else if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
                 outq = fused_tile_full<CHUNKED, DIAG>(t0.q, TT, ti, s, cj, Am, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
                                                 wave_rm);
@@ -3590,11 +3634,19 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
     const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kLutThreads);
 #ifdef MBPE_DIAG
     const int diag = getenv("MBPE_FUSED_DIAG") ? atoi(getenv("MBPE_FUSED_DIAG")) : 0;   // (re-read: set after warm-up)
-    if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_fused_batch<false, false, false, 2>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs,
-                           hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        return;
+#define MBPE_FUSED_DIAG_CASE(D)                                                                                            \
+    if (diag == D && !endbit) {                                                                                            \
+        hipLaunchKernelGGL((k_fused_batch<false, false, false, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,    \
+                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in);                               \
+        hipLaunchKernelGGL((k_fused_batch<false, false, true, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,     \
+                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in);                               \
+        return;                                                                                                            \
     }
+    MBPE_FUSED_DIAG_CASE(2)
+    MBPE_FUSED_DIAG_CASE(3)
+    MBPE_FUSED_DIAG_CASE(4)
+    MBPE_FUSED_DIAG_CASE(5)
+#undef MBPE_FUSED_DIAG_CASE
 #endif
     if (endbit) {
         hipLaunchKernelGGL((k_fused_batch<true, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,

@@ -127,6 +127,7 @@ struct mbpe_ctx {
     bool inert = false;          // whole corpus collapses to one token (NUL quirk, basic)
 
     uint32_t *pc_scratch = nullptr;   // pair-count scan: per-workgroup histogram snapshots (kept for the context's life)
+    uint32_t *pc_bp = nullptr;        // mbpe_pair_count_u8: the 65,536-entry result table
     void *first_state = nullptr;      // `first` tie-break scratch (training)
 
     // slot stream
@@ -394,6 +395,7 @@ void mbpe_destroy(mbpe_ctx *c) {
     free_training(c);
     free_corpus(c);
     dfree(c->pc_scratch);
+    dfree(c->pc_bp);
     if (c->nccl_comm && rccl().ok) rccl().CommDestroy(c->nccl_comm);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->kev_f) (void)hipEventDestroy(e);
@@ -568,8 +570,8 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
     HIPCHK(hipSetDevice(c->device));
     int rcs = ensure_pc_scratch(c);
     if (rcs != MBPE_OK) return rcs;
-    uint32_t *bp = nullptr;
-    HIPCHK(hipMalloc(&bp, 65536 * 4));
+    if (!c->pc_bp) HIPCHK(hipMalloc(&c->pc_bp, 65536 * 4));
+    uint32_t *bp = c->pc_bp;
     HIPCHK(hipMemsetAsync(bp, 0, 65536 * 4, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (!c->inert) launch_pair_count_u8(c->stream, c->d_text, c->n_bytes, c->d_endmask, bp, c->n_cus, c->pc_scratch);
@@ -577,7 +579,6 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && table65536_out) e = hipMemcpy(table65536_out, bp, 65536 * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(bp);
     if (e != hipSuccess) { mbpe_host::set_last_error(hip_err("pair count", e)); return MBPE_ERR_HIP; }
     HIPCHK(hipEventElapsedTime(&c->stats.ms_pair_count, c->ev0, c->ev1));
     c->stats.pair_count_launches++;
