@@ -41,6 +41,16 @@ def main():
             w = [x for x in v if x >= 20.0]
             print("%s,%d,%.3f,%d,%.3f,%.2f,%.2f" % (k, len(v), sum(v) / 1e3, len(w), sum(w) / 1e3,
                                                   sum(w) / max(len(w), 1), max(v)))
+    elif mode == "trace20":
+        # the driver's timed region: the k_fused_batch working dispatches number 6..25 (5 warm-up sequences,
+        # 20 timed ones; the first passes of a run are fused from the second sequence on) and everything between
+        rows = [r for r in csv.DictReader(open(path)) if short(r["Kernel_Name"])]
+        rows.sort(key=lambda r: float(r["Start_Timestamp"]))
+        fused = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith("k_fused_batch")
+                 and float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) >= 20e3]
+        print("k_fused_batch working dispatch,duration_us")
+        for n, i in enumerate(fused[:40]):
+            print("%d,%.2f" % (n, (float(rows[i]["End_Timestamp"]) - float(rows[i]["Start_Timestamp"])) / 1e3))
     elif mode == "sq":
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(path)):
