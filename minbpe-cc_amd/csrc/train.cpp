@@ -20,7 +20,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace mbpe;
@@ -72,6 +74,13 @@ void dfree(T *&p) {
 }
 
 }  // namespace
+
+struct mbpe_ctx;
+namespace {
+template <typename T> hipError_t tmalloc(mbpe_ctx *c, T **p, size_t bytes);
+template <typename T> void tfree(mbpe_ctx *c, T *&p);
+void pool_trim(mbpe_ctx *c);
+}
 
 // ---- RCCL, bound at run time: the library loads and runs on one GPU without it ----
 namespace {
@@ -198,9 +207,62 @@ struct mbpe_ctx {
     std::vector<uint32_t> h_seq_flags;
 
     mbpe_stats stats = {};
+
+    // Device buffers of a training run are kept when the run ends and handed out again to the next one that asks
+    // for the same sizes (mbpe_train_begin twice on one corpus: no 25 GB of hipFree / hipMalloc in between).
+    std::unordered_map<void *, size_t> pool_live;
+    std::multimap<size_t, void *> pool_idle;
 };
 
 namespace {
+
+template <typename T>
+hipError_t tmalloc(mbpe_ctx *c, T **p, size_t bytes) {
+    if (bytes == 0) bytes = 4;
+    auto it = c->pool_idle.find(bytes);
+    if (it != c->pool_idle.end()) {
+        *p = static_cast<T *>(it->second);
+        c->pool_live[it->second] = bytes;
+        c->pool_idle.erase(it);
+        return hipSuccess;
+    }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e == hipErrorOutOfMemory && !c->pool_idle.empty()) {       // give the idle buffers back and retry
+        pool_trim(c);
+        e = hipMalloc(&q, bytes);
+    }
+    if (e != hipSuccess) return e;
+    c->pool_live[q] = bytes;
+    *p = static_cast<T *>(q);
+    return hipSuccess;
+}
+
+template <typename T>
+void tfree(mbpe_ctx *c, T *&p) {
+    if (!p) return;
+    auto it = c->pool_live.find((void *)p);
+    if (it != c->pool_live.end()) {
+        c->pool_idle.emplace(it->second, it->first);
+        c->pool_live.erase(it);
+    } else {
+        (void)hipFree((void *)p);
+    }
+    p = nullptr;
+}
+
+// a buffer that leaves the pool for good (freed right away)
+template <typename T>
+void trelease(mbpe_ctx *c, T *p) {
+    if (!p) return;
+    c->pool_live.erase((void *)p);
+    (void)hipFree((void *)p);
+}
+
+void pool_trim(mbpe_ctx *c) {
+    for (auto &kv : c->pool_idle) (void)hipFree(kv.second);
+    c->pool_idle.clear();
+}
 
 int sync_ctl(mbpe_ctx *c) {
     HIPCHK(hipMemcpyAsync(&c->h_ctl, c->ctl, sizeof(DevCtl), hipMemcpyDeviceToHost, c->stream));
@@ -220,14 +282,14 @@ int sync_ctl(mbpe_ctx *c) {
 }
 
 void free_training(mbpe_ctx *c) {
-    dfree(c->tok[0]); dfree(c->tok[1]);
-    dfree(c->sums); dfree(c->side); dfree(c->chg); dfree(c->tile_list);
-    dfree(c->offsets);
-    dfree(c->tab.hslot); dfree(c->tab.ekey); dfree(c->tab.ecnt); dfree(c->tab.cells);
-    dfree(c->tab.bmax); dfree(c->tab.smax);
-    dfree(c->bp); dfree(c->ctl); dfree(c->best); dfree(c->xb); dfree(c->xb0);
-    dfree(c->d_left); dfree(c->d_right); dfree(c->bs); dfree(c->sel); dfree(c->seq_flags); dfree(c->run_in);
-    if (c->first_state) { (void)hipFree(c->first_state); c->first_state = nullptr; }
+    tfree(c, c->tok[0]); tfree(c, c->tok[1]);
+    tfree(c, c->sums); tfree(c, c->side); tfree(c, c->chg); tfree(c, c->tile_list);
+    tfree(c, c->offsets);
+    tfree(c, c->tab.hslot); tfree(c, c->tab.ekey); tfree(c, c->tab.ecnt); tfree(c, c->tab.cells);
+    tfree(c, c->tab.bmax); tfree(c, c->tab.smax);
+    tfree(c, c->bp); tfree(c, c->ctl); tfree(c, c->best); tfree(c, c->xb); tfree(c, c->xb0);
+    tfree(c, c->d_left); tfree(c, c->d_right); tfree(c, c->bs); tfree(c, c->sel); tfree(c, c->seq_flags); tfree(c, c->run_in);
+    tfree(c, c->first_state);
     c->LR = nullptr;
     c->pending = 0;
     c->begun = false;
@@ -256,11 +318,11 @@ int alloc_table_dense(mbpe_ctx *c) {
     c->tab.vshift = vshift;
     c->tab.ecap = 1u << (2 * vshift);                 // <= 2^30 cells
     const size_t cells = (size_t)1 << (2 * vshift);
-    HIPCHK(hipMalloc(&c->tab.cells, cells * 4));
+    HIPCHK(tmalloc(c, &c->tab.cells, cells * 4));
     HIPCHK(hipMemsetAsync(c->tab.cells, 0, cells * 4, c->stream));
     const size_t nb = (cells >> kBlockShift) + 2, ns = (cells >> (2 * kBlockShift)) + 2;
-    HIPCHK(hipMalloc(&c->tab.bmax, nb * 8));
-    HIPCHK(hipMalloc(&c->tab.smax, ns * 8));
+    HIPCHK(tmalloc(c, &c->tab.bmax, nb * 8));
+    HIPCHK(tmalloc(c, &c->tab.smax, ns * 8));
     HIPCHK(hipMemsetAsync(c->tab.bmax, 0, nb * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->tab.smax, 0, ns * 8, c->stream));
     return MBPE_OK;
@@ -270,12 +332,12 @@ int alloc_table(mbpe_ctx *c, uint32_t ecap) {
     c->tab.ecap = ecap;
     c->hcap = next_pow2((uint64_t)ecap * 2);
     c->tab.hmask = c->hcap - 1;
-    HIPCHK(hipMalloc(&c->tab.hslot, (size_t)c->hcap * 8));
-    HIPCHK(hipMalloc(&c->tab.ekey, (size_t)ecap * 4));
-    HIPCHK(hipMalloc(&c->tab.ecnt, (size_t)ecap * 4));
+    HIPCHK(tmalloc(c, &c->tab.hslot, (size_t)c->hcap * 8));
+    HIPCHK(tmalloc(c, &c->tab.ekey, (size_t)ecap * 4));
+    HIPCHK(tmalloc(c, &c->tab.ecnt, (size_t)ecap * 4));
     const size_t nb = ((size_t)ecap >> kBlockShift) + 2, ns = ((size_t)ecap >> (2 * kBlockShift)) + 2;
-    HIPCHK(hipMalloc(&c->tab.bmax, nb * 8));
-    HIPCHK(hipMalloc(&c->tab.smax, ns * 8));
+    HIPCHK(tmalloc(c, &c->tab.bmax, nb * 8));
+    HIPCHK(tmalloc(c, &c->tab.smax, ns * 8));
     HIPCHK(hipMemsetAsync(c->tab.bmax, 0, nb * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->tab.smax, 0, ns * 8, c->stream));
     launch_fill_u32(c->stream, reinterpret_cast<uint32_t *>(c->tab.hslot), (uint64_t)c->hcap * 2, 0xFFFFFFFFu);
@@ -324,8 +386,8 @@ int grow_table(mbpe_ctx *c, uint64_t want) {
                           hipMemcpyDeviceToDevice, c->stream));
     launch_table_rehash(c->stream, c->tab, c->ctl);
     HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(old.hslot); (void)hipFree(old.ekey); (void)hipFree(old.ecnt);
-    (void)hipFree(old.bmax); (void)hipFree(old.smax);
+    trelease(c, old.hslot); trelease(c, old.ekey); trelease(c, old.ecnt);
+    trelease(c, old.bmax); trelease(c, old.smax);
     return MBPE_OK;
 }
 
@@ -393,6 +455,7 @@ void mbpe_destroy(mbpe_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_training(c);
+    pool_trim(c);
     free_corpus(c);
     dfree(c->pc_scratch);
     dfree(c->pc_bp);
@@ -616,37 +679,37 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     c->n_tiles = (uint32_t)(c->n_slots / kTile);
     c->hdr_words = exchange_header_words(c->n_ranks);
     c->hdrb_words = (batch_header_words() + 3) / 4 * 4;
-    for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->tok[i], c->cap_slots * 2));
-    HIPCHK(hipMalloc(&c->sums, (size_t)c->n_tiles * sizeof(TileSum)));
-    HIPCHK(hipMalloc(&c->side, (size_t)c->n_tiles * sizeof(TileSum)));
-    HIPCHK(hipMalloc(&c->chg, ((size_t)c->n_tiles / 32 + 2) * 4));
-    HIPCHK(hipMalloc(&c->tile_list, ((size_t)c->n_tiles + 64) * 4));
+    for (int i = 0; i < 2; ++i) HIPCHK(tmalloc(c, &c->tok[i], c->cap_slots * 2));
+    HIPCHK(tmalloc(c, &c->sums, (size_t)c->n_tiles * sizeof(TileSum)));
+    HIPCHK(tmalloc(c, &c->side, (size_t)c->n_tiles * sizeof(TileSum)));
+    HIPCHK(tmalloc(c, &c->chg, ((size_t)c->n_tiles / 32 + 2) * 4));
+    HIPCHK(tmalloc(c, &c->tile_list, ((size_t)c->n_tiles + 64) * 4));
     HIPCHK(hipMemsetAsync(c->chg, 0, ((size_t)c->n_tiles / 32 + 2) * 4, c->stream));
-    HIPCHK(hipMalloc(&c->offsets, ((size_t)c->n_tiles + tile_scan_scratch(c->n_tiles)) * 8));
+    HIPCHK(tmalloc(c, &c->offsets, ((size_t)c->n_tiles + tile_scan_scratch(c->n_tiles)) * 8));
     const size_t xb_words = (size_t)c->hdr_words + c->hdrb_words + 2 * (size_t)kBatchMax * vocab_size + 8;
     const size_t xb0_words = 65536 + (size_t)c->hdr_words;
-    HIPCHK(hipMalloc(&c->xb, xb_words * 4));
-    HIPCHK(hipMalloc(&c->xb0, xb0_words * 4));
+    HIPCHK(tmalloc(c, &c->xb, xb_words * 4));
+    HIPCHK(tmalloc(c, &c->xb0, xb0_words * 4));
     HIPCHK(hipMemsetAsync(c->xb, 0, xb_words * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->xb0, 0, xb0_words * 4, c->stream));
     c->hdr_m = c->xb + c->hdr_words;
     c->hdr_adj = c->hdr_m + kBatchMax;
     c->LR = c->xb + c->hdr_words + c->hdrb_words;
-    HIPCHK(hipMalloc(&c->bs, sizeof(BatchState)));
-    HIPCHK(hipMalloc(&c->sel, sizeof(SelList)));
-    HIPCHK(hipMalloc(&c->run_in, ((size_t)c->n_tiles + 64) * 4));
-    HIPCHK(hipMalloc(&c->seq_flags, 4096 * 4));
+    HIPCHK(tmalloc(c, &c->bs, sizeof(BatchState)));
+    HIPCHK(tmalloc(c, &c->sel, sizeof(SelList)));
+    HIPCHK(tmalloc(c, &c->run_in, ((size_t)c->n_tiles + 64) * 4));
+    HIPCHK(tmalloc(c, &c->seq_flags, 4096 * 4));
     HIPCHK(hipMemsetAsync(c->bs, 0, sizeof(BatchState), c->stream));
     if (c->opt_first) {
-        HIPCHK(hipMalloc(&c->first_state, first_state_bytes()));
+        HIPCHK(tmalloc(c, &c->first_state, first_state_bytes()));
         launch_first_init(c->stream, c->first_state);
     }
     c->k_upper = 0;
     c->bp = nullptr;   // the byte-pair table lives at the front of xb0
-    HIPCHK(hipMalloc(&c->d_left, sizeof(RankEdge)));
-    HIPCHK(hipMalloc(&c->d_right, sizeof(RankEdge)));
-    HIPCHK(hipMalloc(&c->ctl, sizeof(DevCtl)));
-    HIPCHK(hipMalloc(&c->best, ((size_t)c->n_target + 2) * 8));
+    HIPCHK(tmalloc(c, &c->d_left, sizeof(RankEdge)));
+    HIPCHK(tmalloc(c, &c->d_right, sizeof(RankEdge)));
+    HIPCHK(tmalloc(c, &c->ctl, sizeof(DevCtl)));
+    HIPCHK(tmalloc(c, &c->best, ((size_t)c->n_target + 2) * 8));
     {
         DevCtl init = {};
         init.n_live = n;         // every corpus byte starts as one live token
@@ -667,6 +730,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
 
     rc = ensure_pc_scratch(c);
     if (rc != MBPE_OK) return rc;
+    pool_trim(c);        // what this run did not take over from the previous one goes back to the driver
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (n >= 2) launch_pair_count_u8(c->stream, c->d_text, n, c->d_endmask, c->xb0, c->n_cus, c->pc_scratch);
     c->cur = 0;
