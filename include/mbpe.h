@@ -1,7 +1,7 @@
 /*
  * mbpe.h -- C-ABI of the MI355X-native BPE trainer hot path.
  *
- * Drop-in boundary for justinhj/minbpe-cc's lexical-tie-break training path.
+ * Drop-in boundary for justinhj/minbpe-cc's training path (both tie-breaks) and its encode.
  * The reference has no FFI layer of its own; every entry point
  * below names the reference code it replaces (paths relative to the
  * reference checkout, code/include/...).  INTEGRATION.md shows the binding a

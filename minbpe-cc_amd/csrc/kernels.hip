@@ -2460,6 +2460,77 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     }
 }
 
+// ---- count updates off the streaming waves' critical path -------------------------------------------
+// A fused pass issues two scattered global atomics per match (L_j[x], R_j[y]) plus one per changed tile (its
+// mark).  Scattered atomics execute at the memory side at a few tens of G/s, and a wave that issued some must
+// wait for them before it can use its next prefetched tile (vmcnt counts loads, stores and atomics together,
+// in order): on the benchmark that wait was a quarter of the pass.  So the streaming waves do not issue them:
+// they append 4-byte records to a ring in LDS, and one extra wave per workgroup drains the ring and issues
+// the atomics fire-and-forget, thousands in flight, never waiting for one.
+//   record = kind << 30 | index:  0: LR[index] += 1   1: LR[index] -= 1   2: hdr_adj[index] += 1
+//                                 3: chg bit of tile `index`
+// Slots are handed out by an LDS counter (one returning add per wave and call), a slot holds kRingEmpty
+// until its record is written, the drain wave resets a slot before it moves `head` past it, and a producer
+// only writes a slot once `head` has passed the slot's previous use: no record is lost or read twice.
+constexpr uint32_t kRingSize = 1024;
+constexpr uint32_t kRingEmpty = 0xFFFFFFFFu;
+struct DeltaRing {
+    uint32_t tail, head, done, pad;
+    uint32_t rec[kRingSize];
+};
+
+__device__ __forceinline__ void ring_init(DeltaRing &r) {
+    for (uint32_t i = threadIdx.x; i < kRingSize; i += blockDim.x) r.rec[i] = kRingEmpty;
+    if (threadIdx.x == 0) { r.tail = 0; r.head = 0; r.done = 0; }
+}
+
+// every active lane appends one record (called from divergent code)
+__device__ __forceinline__ void ring_push(DeltaRing &r, uint32_t rec) {
+    const unsigned long long act = __ballot(true);
+    const uint32_t lane = lane_id();
+    const uint32_t n = (uint32_t)__popcll(act);
+    uint32_t pos = 0;
+    if (lane == (uint32_t)__builtin_ctzll(act)) pos = atomicAdd(&r.tail, n);
+    pos = rfl(pos);                                   // the first active lane is the one that asked
+    while ((int32_t)(pos + n - __hip_atomic_load(&r.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >
+           (int32_t)kRingSize)
+        __builtin_amdgcn_s_sleep(1);
+    const uint32_t slot = (pos + (uint32_t)__popcll(act & ((1ull << lane) - 1ull))) & (kRingSize - 1u);
+    __hip_atomic_store(&r.rec[slot], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// the drain wave: until all `producers` waves have signed off and the ring is empty
+__device__ __forceinline__ void ring_drain(DeltaRing &r, uint32_t producers, uint32_t *LR, uint32_t *hdr_adj,
+                                           uint32_t *chg) {
+    const uint32_t lane = lane_id();
+    uint32_t head = 0;
+    for (;;) {
+        const uint32_t done = __hip_atomic_load(&r.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t tail = __hip_atomic_load(&r.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t avail = tail - head;
+        if (avail == 0u) {
+            if (done == producers) break;             // (`done` was read before `tail`: nothing can follow)
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        const uint32_t k = avail < (uint32_t)kWave ? avail : (uint32_t)kWave;
+        if (lane < k) {
+            const uint32_t slot = (head + lane) & (kRingSize - 1u);
+            uint32_t rec;
+            while ((rec = __hip_atomic_load(&r.rec[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kRingEmpty)
+                __builtin_amdgcn_s_sleep(1);          // handed out, not written yet
+            __hip_atomic_store(&r.rec[slot], kRingEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t kind = rec >> 30, idx = rec & 0x3FFFFFFFu;
+            if (kind == 0u) atomicAdd(&LR[idx], 1u);
+            else if (kind == 1u) atomicAdd(&LR[idx], 0xFFFFFFFFu);
+            else if (kind == 2u) atomicAdd(&hdr_adj[idx], 1u);
+            else atomicOr(&chg[idx >> 5], 1u << (idx & 31u));
+        }
+        head += k;
+        if (lane == 0) __hip_atomic_store(&r.head, head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 // ---- the fused pass of a large batch ----------------------------------------------------
 // With several dozen pairs in a batch most tiles hold a match, so the separate
 // "count, validate, rewrite the marked tiles" scheme reads the stream nearly
@@ -2485,7 +2556,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
-                                                 DeltaCache &dc, bool dc_on, uint32_t &wave_rm) {
+                                                 DeltaCache &dc, bool dc_on, uint32_t &wave_rm, DeltaRing *ring) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     // (an opaque copy of the lane id: the 64-bit lane masks below are cheaper to rebuild per tile than
@@ -2563,8 +2634,15 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
             nv = is_a ? (X0 + ja) | (cj[j] & endbit) : kHole;
             if (counted && DIAG != 2) {
                 if (is_a && ((touch >> j) & 1u)) {        // ... (a', b') (a, b): (b', a) -> (X', X)
-                    atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
-                    dc_add(dc, dc_on, LR, lr_idx(self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b')
+                    if (ring) {
+                        ring_push(*ring, (2u << 30) | (pjb * kBatchMax + ja));
+                        ring_push(*ring, (1u << 30) | lr_idx(self, pjb, 1));
+                    } else {
+                        atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
+                        dc_add(dc, dc_on, LR, lr_idx(self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b')
+                    }
+                } else if (ring) {
+                    ring_push(*ring, lr_idx(nb & idmask, ja, is_a ? 0u : 1u));
                 } else {
                     dc_add(dc, dc_on, LR, lr_idx(nb & idmask, ja, is_a ? 0u : 1u), 1u);
                 }
@@ -2602,7 +2680,8 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
     }
     if (lane == 0) {
         reinterpret_cast<uint4 *>(sout)[tile] = ns;
-        atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
+        if (ring) ring_push(*ring, (3u << 30) | tile);
+        else atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
     }
     return pack8(out);
 }
@@ -2615,8 +2694,10 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
 #ifndef MBPE_FUSED_WAVES
 #define MBPE_FUSED_WAVES 4
 #endif
+// (the instantiations without the delta cache run one wave more per workgroup: the drain wave of the ring)
+template <bool HOT> constexpr int fused_threads() { return HOT ? kLutThreads : kLutThreads + kWave; }
 template <bool CHUNKED, bool HOT, bool TT, int DIAG = 0>
-__global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
+__global__ __launch_bounds__(fused_threads<HOT>(), MBPE_FUSED_WAVES * 256 / kLutThreads) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
                                                                const TileSum *__restrict__ sin,
                                                                TileSum *__restrict__ sout, uint32_t n_tiles,
                                                                uint32_t *__restrict__ chg, const BatchState *bs,
@@ -2639,11 +2720,18 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     const uint32_t X0 = 256u + ctl->k_done;
     if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
+    constexpr bool use_ring = !HOT;
+    __shared__ DeltaRing ring_mem;
+    DeltaRing *ring = use_ring ? &ring_mem : nullptr;
     if (dc_on) dc_init(dc);
+    if (use_ring) ring_init(ring_mem);
     lut_build(lut, bs, n_keys, idmask - 1u);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     uint32_t wave_rm = 0;        // uniform
+    if (use_ring && threadIdx.x >= (uint32_t)kLutThreads) {
+        ring_drain(ring_mem, waves_per_block, LR, hdr_adj, chg);
+    } else {
     if (tile < n_tiles) {
 
     const uint32_t last_tile = n_tiles - 1;
@@ -2713,7 +2801,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             } else if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
                 outq = fused_tile_full<CHUNKED, DIAG>(t0.q, TT, ti, s, cj, Am, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
-                                                wave_rm);
+                                                wave_rm, ring);
             }
         }
         MBPE_GLOBAL_AS char *obase =
@@ -2726,6 +2814,8 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
         t0 = t1; t1 = t2;
         v1 = v2;
     }
+    }
+    if (use_ring && lane == 0) atomicAdd(&ring_mem.done, 1u);       // this wave appends nothing more
     }
     if (dc_on) dc_flush(dc, LR);
     if (lane == 0 && wave_rm) atomicAdd(&ctl->rm, wave_rm);
@@ -3629,9 +3719,11 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
                         int n_cus, uint32_t *hdr_m, const uint32_t *run_in) {
     if (!n_tiles) return;
-    static const int occ_c = resident_blocks(k_fused_batch<true, false, false, 0>, kLutThreads),
-                     occ_b = resident_blocks(k_fused_batch<false, false, false, 0>, kLutThreads);
-    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kLutThreads);
+    constexpr int kRingThreads = kLutThreads + kWave;      // + the drain wave (fused_threads<false>())
+    static const int occ_c = resident_blocks(k_fused_batch<true, false, false, 0>, kRingThreads),
+                     occ_b = resident_blocks(k_fused_batch<false, false, false, 0>, kRingThreads);
+    // (the grid counts the streaming waves: kLutThreads / 64 per workgroup in every instantiation)
+    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kRingThreads), block_hot(kLutThreads);
 #ifdef MBPE_DIAG
     const int diag = getenv("MBPE_FUSED_DIAG") ? atoi(getenv("MBPE_FUSED_DIAG")) : 0;   // (re-read: set after warm-up)
 #define MBPE_FUSED_DIAG_CASE(D)                                                                                            \
@@ -3653,18 +3745,18 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
         hipLaunchKernelGGL((k_fused_batch<true, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        hipLaunchKernelGGL((k_fused_batch<true, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+        hipLaunchKernelGGL((k_fused_batch<true, true, false>), grid, block_hot, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        hipLaunchKernelGGL((k_fused_batch<true, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+        hipLaunchKernelGGL((k_fused_batch<true, true, true>), grid, block_hot, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
     } else {
         hipLaunchKernelGGL((k_fused_batch<false, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
         hipLaunchKernelGGL((k_fused_batch<false, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        hipLaunchKernelGGL((k_fused_batch<false, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+        hipLaunchKernelGGL((k_fused_batch<false, true, false>), grid, block_hot, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        hipLaunchKernelGGL((k_fused_batch<false, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+        hipLaunchKernelGGL((k_fused_batch<false, true, true>), grid, block_hot, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
     }
 }
