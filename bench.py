@@ -276,7 +276,26 @@ def main():
                     "begin_ms": fs["ms_begin"], "steps_ms": fs["ms_steps"], "compactions": fs["n_compactions"],
                     "live_end": fs["n_live"], "slots_end": fs["n_slots"], "pairs": fs["n_pairs"],
                     "includes": "pair-count scan, stream + table setup, every sequence, host housekeeping"}
-        rt = C.decode_roundtrip(tr, merges, corpus, torch, device)
+        if dist is None:
+            ref = corpus
+        else:
+            # a merge that straddles two shards leaves its token with the left one: this rank's stream decodes to
+            # the corpus bytes that follow those of the ranks before it, whatever range it was loaded with
+            mine = C.decoded_length(tr, merges, torch, device)
+            lens = [None] * world
+            dist.all_gather_object(lens, mine)
+            start = sum(lens[:rank])
+            if bible:
+                _, whole = bible_standin_device(device, 0, total_bytes)
+                ref = whole[start:start + mine]
+            else:
+                a0 = start // 8 * 8
+                _, piece = splitmix64_device(args.seed, start - a0 + mine, device, a0)
+                ref = piece[start - a0:]
+        rt = C.decode_roundtrip(tr, merges, ref, torch, device)
+        if dist is not None:
+            rt["decoded_total_all_ranks"] = int(sum(lens))
+            rt["ok"] = bool(rt["ok"] and sum(lens) == total_bytes)
         digest = hashlib.sha256(merges.tobytes() + counts.tobytes()).hexdigest()
         same = True
         if dist is not None:

@@ -280,8 +280,8 @@ __global__ void k_fill_u16(uint16_t *p, uint64_t n, uint16_t v) {
 //     segment is recounted by the slow loop, which sweeps every 49,152 increments and
 //     moves counters >= 0x2000 to the global table, so that none can wrap.
 // After a good segment counters >= 0x2000 are drained as well (the slow loop relies on it).
-// Segment length adapts: it doubles while the largest counter stays small and restarts at
-// kPcSeg0 iterations after a void segment.  Uniform data never takes the slow loop; a
+// Segment length adapts: it starts at kPcSeg0 iterations, grows (x8, x2) while the largest counter stays
+// small and shrinks to a quarter (at least 8) after a void segment.  Uniform data never takes the slow loop; a
 // corpus that is one repeated byte takes it for every segment.
 constexpr int kPcThreads = 1024;
 constexpr int kPcWords = 32768;            // 2 counters per word
@@ -289,7 +289,7 @@ constexpr uint32_t kPcHotBits = 0xE000u;   // counter >= 0x2000
 constexpr int kPcEpochIters = 3;           // slow loop: iterations of one vector per lane between sweeps
 constexpr int kPcVpl = 2;                  // fast loop: vectors per lane and iteration
 #ifndef MBPE_PC_SEG0
-#define MBPE_PC_SEG0 32
+#define MBPE_PC_SEG0 64
 #endif
 constexpr uint32_t kPcSeg0 = MBPE_PC_SEG0;  // first segment, in fast iterations of 32 Ki pairs
 constexpr uint32_t kPcSegMax = 4096;
@@ -498,8 +498,9 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__r
                 ck = pc_check(hist, 0, red);
             }
             resid = ck.sum;
-            if (ck.max < 0x0800u && seg_iters * 4 <= kPcSegMax) seg_iters *= 4;
-            else if (ck.max < 0x1000u && seg_iters * 2 <= kPcSegMax) seg_iters *= 2;
+            // (the next segment may be as long as keeps the largest counter, growing at this rate, below half)
+            if (ck.max * 8u < 0x8000u && seg_iters * 8 <= kPcSegMax) seg_iters *= 8;
+            else if (ck.max * 2u < 0x8000u && seg_iters * 2 <= kPcSegMax) seg_iters *= 2;
             else if (ck.max >= 0x8000u && seg_iters > 4) seg_iters /= 2;
         } else {
             // a counter wrapped: the segment is void.  Restore and recount it with sweeps
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__r
             pc_sweep(hist, bp);
             __syncthreads();
             resid = pc_check(hist, 0, red).sum;
-            seg_iters = kPcSeg0;
+            seg_iters = seg_iters >= 32 ? seg_iters / 4 : 8;      // shorter segments while the data stay this skewed
         }
         seg = seg_end;
     }
@@ -2460,77 +2461,6 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     }
 }
 
-// ---- count updates off the streaming waves' critical path -------------------------------------------
-// A fused pass issues two scattered global atomics per match (L_j[x], R_j[y]) plus one per changed tile (its
-// mark).  Scattered atomics execute at the memory side at a few tens of G/s, and a wave that issued some must
-// wait for them before it can use its next prefetched tile (vmcnt counts loads, stores and atomics together,
-// in order): on the benchmark that wait was a quarter of the pass.  So the streaming waves do not issue them:
-// they append 4-byte records to a ring in LDS, and one extra wave per workgroup drains the ring and issues
-// the atomics fire-and-forget, thousands in flight, never waiting for one.
-//   record = kind << 30 | index:  0: LR[index] += 1   1: LR[index] -= 1   2: hdr_adj[index] += 1
-//                                 3: chg bit of tile `index`
-// Slots are handed out by an LDS counter (one returning add per wave and call), a slot holds kRingEmpty
-// until its record is written, the drain wave resets a slot before it moves `head` past it, and a producer
-// only writes a slot once `head` has passed the slot's previous use: no record is lost or read twice.
-constexpr uint32_t kRingSize = 1024;
-constexpr uint32_t kRingEmpty = 0xFFFFFFFFu;
-struct DeltaRing {
-    uint32_t tail, head, done, pad;
-    uint32_t rec[kRingSize];
-};
-
-__device__ __forceinline__ void ring_init(DeltaRing &r) {
-    for (uint32_t i = threadIdx.x; i < kRingSize; i += blockDim.x) r.rec[i] = kRingEmpty;
-    if (threadIdx.x == 0) { r.tail = 0; r.head = 0; r.done = 0; }
-}
-
-// every active lane appends one record (called from divergent code)
-__device__ __forceinline__ void ring_push(DeltaRing &r, uint32_t rec) {
-    const unsigned long long act = __ballot(true);
-    const uint32_t lane = lane_id();
-    const uint32_t n = (uint32_t)__popcll(act);
-    uint32_t pos = 0;
-    if (lane == (uint32_t)__builtin_ctzll(act)) pos = atomicAdd(&r.tail, n);
-    pos = rfl(pos);                                   // the first active lane is the one that asked
-    while ((int32_t)(pos + n - __hip_atomic_load(&r.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >
-           (int32_t)kRingSize)
-        __builtin_amdgcn_s_sleep(1);
-    const uint32_t slot = (pos + (uint32_t)__popcll(act & ((1ull << lane) - 1ull))) & (kRingSize - 1u);
-    __hip_atomic_store(&r.rec[slot], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// the drain wave: until all `producers` waves have signed off and the ring is empty
-__device__ __forceinline__ void ring_drain(DeltaRing &r, uint32_t producers, uint32_t *LR, uint32_t *hdr_adj,
-                                           uint32_t *chg) {
-    const uint32_t lane = lane_id();
-    uint32_t head = 0;
-    for (;;) {
-        const uint32_t done = __hip_atomic_load(&r.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t tail = __hip_atomic_load(&r.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t avail = tail - head;
-        if (avail == 0u) {
-            if (done == producers) break;             // (`done` was read before `tail`: nothing can follow)
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-        }
-        const uint32_t k = avail < (uint32_t)kWave ? avail : (uint32_t)kWave;
-        if (lane < k) {
-            const uint32_t slot = (head + lane) & (kRingSize - 1u);
-            uint32_t rec;
-            while ((rec = __hip_atomic_load(&r.rec[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kRingEmpty)
-                __builtin_amdgcn_s_sleep(1);          // handed out, not written yet
-            __hip_atomic_store(&r.rec[slot], kRingEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t kind = rec >> 30, idx = rec & 0x3FFFFFFFu;
-            if (kind == 0u) atomicAdd(&LR[idx], 1u);
-            else if (kind == 1u) atomicAdd(&LR[idx], 0xFFFFFFFFu);
-            else if (kind == 2u) atomicAdd(&hdr_adj[idx], 1u);
-            else atomicOr(&chg[idx >> 5], 1u << (idx & 31u));
-        }
-        head += k;
-        if (lane == 0) __hip_atomic_store(&r.head, head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-
 // ---- the fused pass of a large batch ----------------------------------------------------
 // With several dozen pairs in a batch most tiles hold a match, so the separate
 // "count, validate, rewrite the marked tiles" scheme reads the stream nearly
@@ -2556,7 +2486,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
-                                                 DeltaCache &dc, bool dc_on, uint32_t &wave_rm, DeltaRing *ring) {
+                                                 DeltaCache &dc, bool dc_on, uint32_t &wave_rm) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     // (an opaque copy of the lane id: the 64-bit lane masks below are cheaper to rebuild per tile than
@@ -2634,15 +2564,8 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
             nv = is_a ? (X0 + ja) | (cj[j] & endbit) : kHole;
             if (counted && DIAG != 2) {
                 if (is_a && ((touch >> j) & 1u)) {        // ... (a', b') (a, b): (b', a) -> (X', X)
-                    if (ring) {
-                        ring_push(*ring, (2u << 30) | (pjb * kBatchMax + ja));
-                        ring_push(*ring, (1u << 30) | lr_idx(self, pjb, 1));
-                    } else {
-                        atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
-                        dc_add(dc, dc_on, LR, lr_idx(self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b')
-                    }
-                } else if (ring) {
-                    ring_push(*ring, lr_idx(nb & idmask, ja, is_a ? 0u : 1u));
+                    atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
+                    dc_add(dc, dc_on, LR, lr_idx(self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b')
                 } else {
                     dc_add(dc, dc_on, LR, lr_idx(nb & idmask, ja, is_a ? 0u : 1u), 1u);
                 }
@@ -2680,8 +2603,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
     }
     if (lane == 0) {
         reinterpret_cast<uint4 *>(sout)[tile] = ns;
-        if (ring) ring_push(*ring, (3u << 30) | tile);
-        else atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
+        atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
     }
     return pack8(out);
 }
@@ -2694,10 +2616,8 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
 #ifndef MBPE_FUSED_WAVES
 #define MBPE_FUSED_WAVES 4
 #endif
-// (the instantiations without the delta cache run one wave more per workgroup: the drain wave of the ring)
-template <bool HOT> constexpr int fused_threads() { return HOT ? kLutThreads : kLutThreads + kWave; }
 template <bool CHUNKED, bool HOT, bool TT, int DIAG = 0>
-__global__ __launch_bounds__(fused_threads<HOT>(), MBPE_FUSED_WAVES * 256 / kLutThreads) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
+__global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
                                                                const TileSum *__restrict__ sin,
                                                                TileSum *__restrict__ sout, uint32_t n_tiles,
                                                                uint32_t *__restrict__ chg, const BatchState *bs,
@@ -2720,18 +2640,11 @@ __global__ __launch_bounds__(fused_threads<HOT>(), MBPE_FUSED_WAVES * 256 / kLut
     const uint32_t X0 = 256u + ctl->k_done;
     if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
-    constexpr bool use_ring = !HOT;
-    __shared__ DeltaRing ring_mem;
-    DeltaRing *ring = use_ring ? &ring_mem : nullptr;
     if (dc_on) dc_init(dc);
-    if (use_ring) ring_init(ring_mem);
     lut_build(lut, bs, n_keys, idmask - 1u);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     uint32_t wave_rm = 0;        // uniform
-    if (use_ring && threadIdx.x >= (uint32_t)kLutThreads) {
-        ring_drain(ring_mem, waves_per_block, LR, hdr_adj, chg);
-    } else {
     if (tile < n_tiles) {
 
     const uint32_t last_tile = n_tiles - 1;
@@ -2765,6 +2678,7 @@ __global__ __launch_bounds__(fused_threads<HOT>(), MBPE_FUSED_WAVES * 256 / kLut
             }
             uint32_t lf, c_init, tile_first, cj[8];
             unsigned long long m_live;
+            bool renamed = false;        // uniform: tt_rename ran on this tile (only then can stand-in ids occur in it)
             // (t,t) members: the renaming changes the tile's tokens, so everything derived from them is redone
             // after it -- for the few tiles that need it (tt_needed)
             for (int rep = 0;; ++rep) {
@@ -2788,6 +2702,7 @@ __global__ __launch_bounds__(fused_threads<HOT>(), MBPE_FUSED_WAVES * 256 / kLut
                 }
                 if (!TT || rep || DIAG == 5 || !tt_needed<CHUNKED>(s, cj, h, tile_first, ti)) break;
                 tt_rename<CHUNKED>(s, h, ti, run_in[tile]);
+                renamed = true;
             }
             uint32_t Am = 0;             // bit j: slot j starts a match
 #pragma unroll
@@ -2799,9 +2714,9 @@ __global__ __launch_bounds__(fused_threads<HOT>(), MBPE_FUSED_WAVES * 256 / kLut
             if (DIAG == 3 || DIAG == 5) {    // timing-only build: membership tests, no merge
                 asm volatile("" :: "v"(Am));
             } else if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
-                outq = fused_tile_full<CHUNKED, DIAG>(t0.q, TT, ti, s, cj, Am, m_live, c_init, h, tile_first,
+                outq = fused_tile_full<CHUNKED, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
-                                                wave_rm, ring);
+                                                wave_rm);
             }
         }
         MBPE_GLOBAL_AS char *obase =
@@ -2814,8 +2729,6 @@ __global__ __launch_bounds__(fused_threads<HOT>(), MBPE_FUSED_WAVES * 256 / kLut
         t0 = t1; t1 = t2;
         v1 = v2;
     }
-    }
-    if (use_ring && lane == 0) atomicAdd(&ring_mem.done, 1u);       // this wave appends nothing more
     }
     if (dc_on) dc_flush(dc, LR);
     if (lane == 0 && wave_rm) atomicAdd(&ctl->rm, wave_rm);
@@ -3719,11 +3632,9 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
                         int n_cus, uint32_t *hdr_m, const uint32_t *run_in) {
     if (!n_tiles) return;
-    constexpr int kRingThreads = kLutThreads + kWave;      // + the drain wave (fused_threads<false>())
-    static const int occ_c = resident_blocks(k_fused_batch<true, false, false, 0>, kRingThreads),
-                     occ_b = resident_blocks(k_fused_batch<false, false, false, 0>, kRingThreads);
-    // (the grid counts the streaming waves: kLutThreads / 64 per workgroup in every instantiation)
-    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kRingThreads), block_hot(kLutThreads);
+    static const int occ_c = resident_blocks(k_fused_batch<true, false, false, 0>, kLutThreads),
+                     occ_b = resident_blocks(k_fused_batch<false, false, false, 0>, kLutThreads);
+    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kLutThreads);
 #ifdef MBPE_DIAG
     const int diag = getenv("MBPE_FUSED_DIAG") ? atoi(getenv("MBPE_FUSED_DIAG")) : 0;   // (re-read: set after warm-up)
 #define MBPE_FUSED_DIAG_CASE(D)                                                                                            \
@@ -3745,18 +3656,18 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
         hipLaunchKernelGGL((k_fused_batch<true, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        hipLaunchKernelGGL((k_fused_batch<true, true, false>), grid, block_hot, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+        hipLaunchKernelGGL((k_fused_batch<true, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        hipLaunchKernelGGL((k_fused_batch<true, true, true>), grid, block_hot, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+        hipLaunchKernelGGL((k_fused_batch<true, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
     } else {
         hipLaunchKernelGGL((k_fused_batch<false, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
         hipLaunchKernelGGL((k_fused_batch<false, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        hipLaunchKernelGGL((k_fused_batch<false, true, false>), grid, block_hot, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+        hipLaunchKernelGGL((k_fused_batch<false, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        hipLaunchKernelGGL((k_fused_batch<false, true, true>), grid, block_hot, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+        hipLaunchKernelGGL((k_fused_batch<false, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
     }
 }

@@ -101,6 +101,21 @@ def decode_roundtrip(tr, merges, corpus, torch, device, slots_per_piece=1 << 28)
             "decoded_bytes": base, "max_token_bytes": width}
 
 
+def decoded_length(tr, merges, torch, device, slots_per_piece=1 << 28):
+    """Bytes the live stream of this context decodes to (a shard of a multi-GPU run owns the bytes of its tokens:
+    a merge that straddles two shards leaves the new token with the left one, so a shard's stream need not
+    cover exactly the byte range it was loaded with)."""
+    lens_h, _ = token_tables(merges)
+    lens_t = torch.from_numpy(lens_h).to(device)
+    _, n_slots, _, _ = tr.stream_device()
+    total = 0
+    for lo in range(0, n_slots, slots_per_piece):
+        toks, _ = live_tokens(tr, torch, device, lo, lo + slots_per_piece)
+        if toks.numel():
+            total += int(lens_t[toks.long()].sum())
+    return total
+
+
 def counts_nonincreasing(counts):
     c = np.asarray(counts, dtype=np.int64)
     return bool(np.all(np.diff(c) <= 0))

@@ -50,7 +50,7 @@ def _allreduce(trainers):
         assert hip().hipMemcpy(ptr, total.ctypes.data, n * 4, 1) == 0    # H2D
 
 
-def _train_sharded(data, cuts, vocab, chunk_off=None):
+def _train_sharded(data, cuts, vocab, chunk_off=None, decode_check=False):
     data = np.frombuffer(bytes(data), dtype=np.uint8)
     bounds = [0] + list(cuts) + [len(data)]
     R = len(bounds) - 1
@@ -79,6 +79,21 @@ def _train_sharded(data, cuts, vocab, chunk_off=None):
         results = [t.train_result() for t in trainers]
         streams = [t.stream()[0] for t in trainers]
         tables = [t.pairs_dict() for t in trainers]
+        if decode_check:
+            # bench.py's check of a sharded run: rank r's stream decodes to the corpus bytes that follow
+            # those of the ranks before it (a merge straddling two shards leaves its token with the left one)
+            import torch
+            from mbpe import check as C
+            dev = torch.device("cuda", 0)
+            merges = results[0][0]
+            lens = [C.decoded_length(t, merges, torch, dev) for t in trainers]
+            assert sum(lens) == len(data)
+            whole = torch.from_numpy(data.copy()).to(dev)
+            start = 0
+            for t, n in zip(trainers, lens):
+                rt = C.decode_roundtrip(t, merges, whole[start:start + n], torch, dev)
+                assert rt["ok"], rt
+                start += n
         return results, streams, tables
     finally:
         for t in trainers:
@@ -129,6 +144,14 @@ def test_runs_and_touching_matches_across_the_cut():
     data = b"a" * 3000 + b"b" * 2501 + b"ab" * 100 + b"c" * 1600 + b"b" * 777 + b"a" * 1300
     _check(data, [1000, 4100], 256 + 24)
     _check(data, [2999, 3001, 5501], 256 + 24)
+
+
+def test_sharded_decode_check():
+    # cuts inside matches: shards whose streams begin / end a byte off the range they were loaded with
+    data = np.frombuffer(b"xy" + b"ab" * 3001 + b"z" + b"abc" * 500, dtype=np.uint8)
+    _train_sharded(data, [2 + 3001, 5000], 256 + 12, decode_check=True)
+    data = O.splitmix64_bytes(9, 300000)
+    _train_sharded(data, [100001, 200003], 256 + 200, decode_check=True)
 
 
 def test_empty_and_tiny_shards():
