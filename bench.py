@@ -275,6 +275,9 @@ def main():
                     "passes": fs["n_batches"], "fused_passes": fs["n_fused"], "fused_abandoned": fs["n_fused_dropped"],
                     "begin_ms": fs["ms_begin"], "steps_ms": fs["ms_steps"], "compactions": fs["n_compactions"],
                     "live_end": fs["n_live"], "slots_end": fs["n_slots"], "pairs": fs["n_pairs"],
+                    "selection": {k: fs[k] for k in ("n_sel_retry", "n_sel_fallback", "cut_conflict", "cut_bucket",
+                                                     "cut_single", "cut_full", "n_skipped", "n_skip_cut",
+                                                     "n_validation_drops")},
                     "includes": "pair-count scan, stream + table setup, every sequence, host housekeeping"}
         if dist is None:
             ref = corpus

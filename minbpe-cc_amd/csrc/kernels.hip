@@ -295,7 +295,11 @@ constexpr uint32_t kPcSeg0 = MBPE_PC_SEG0;  // first segment, in fast iterations
 constexpr uint32_t kPcSegMax = 4096;
 
 __device__ __forceinline__ uint32_t pc_table_index(uint32_t hbin) {
+#ifndef MBPE_PC_NOHASH
     const uint32_t bin = hbin ^ (hbin >> 8);         // undo the bank hash
+#else
+    const uint32_t bin = hbin;
+#endif
     return ((bin & 0xFFu) << 8) | (bin >> 8);        // -> (first << 8) | second
 }
 
@@ -326,7 +330,9 @@ __device__ __forceinline__ void pc_sweep(uint32_t *hist, uint32_t *bp) {
 __device__ __forceinline__ void pc_flush(const uint32_t *hist, uint32_t *bp) {
     for (uint32_t o = threadIdx.x; o < 65536u; o += kPcThreads) {
         uint32_t bin = ((o & 0xFFu) << 8) | (o >> 8);
+#ifndef MBPE_PC_NOHASH
         bin ^= bin >> 8;
+#endif
         const uint32_t c = (hist[bin & 0x7FFFu] >> ((bin >> 15) * 16)) & 0xFFFFu;
         if (c) atomicAdd(&bp[o], c);
     }
@@ -430,7 +436,9 @@ __device__ __forceinline__ uint32_t pc_count_range(uint32_t *hist, uint32_t *__r
                     uint32_t bin;
                     if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
                     else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
+#ifndef MBPE_PC_NOHASH
                     bin ^= bin >> 8;
+#endif
                     atomicAdd(&hist[bin & 0x7FFFu], 1u + (bin >> 15) * 0xFFFFu);
                 }
             } else {
@@ -440,7 +448,9 @@ __device__ __forceinline__ uint32_t pc_count_range(uint32_t *hist, uint32_t *__r
                     uint32_t bin;
                     if (sh <= 16) bin = (w[wi] >> sh) & 0xFFFFu;
                     else bin = ((w[wi] >> 24) | (w[wi + 1] << 8)) & 0xFFFFu;
+#ifndef MBPE_PC_NOHASH
                     bin ^= bin >> 8;
+#endif
                     const uint32_t inc = ((valid >> i) & 1u) ? 1u + (bin >> 15) * 0xFFFFu : 0u;   // invalid: add 0
                     atomicAdd(&hist[bin & 0x7FFFu], inc);
                 }
@@ -2121,7 +2131,16 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 // the block bounds give the threshold.
                 const unsigned long long c_hi = sp[0] >> 32, c_lo = sp[n_l - 1] >> 32;
                 unsigned long long spread = c_hi - c_lo > 0 ? c_hi - c_lo : 1;
-                if (spread < 1 + c_lo / 64) spread = 1 + c_lo / 64;
+                if (n_l >= 256u) {
+                    // a long list tells how dense the counts are here (uniform data: thousands of pairs within
+                    // a few hundred counts, where 1/64 of the count would bring back the whole table and send
+                    // every selection through the overflow path): extend by what that density needs
+                    const unsigned long long need = (unsigned long long)(want - n_l) + adapt;
+                    spread = (spread * need + n_l - 1) / n_l;
+                    if (spread < 1) spread = 1;
+                } else if (spread < 1 + c_lo / 64) {
+                    spread = 1 + c_lo / 64;
+                }
                 ctl->sel_T = c_lo > spread ? (c_lo - spread) << 32 : 1ull << 32;
             }
         }

@@ -27,6 +27,52 @@ __global__ void k_atom(uint32_t *tab, uint32_t mask, uint32_t per_lane, uint32_t
     for (uint32_t k = 0; k < per_lane; ++k) atomicAdd(&tab[mix(g * 0x9E3779B97F4A7C15ull + k) & mask], 1u);
 }
 
+// the same with an atomic of narrower scope (is it executed in the XCD's L2 instead of at the memory side?), and
+// with one table per XCD (XCC_ID), which is what such atomics would need to stay exact
+template <int SCOPE, bool PER_XCD>
+__global__ void k_atom_scope(uint32_t *tab, uint32_t mask, uint32_t per_lane, uint32_t active) {
+    const uint32_t lane = threadIdx.x & 63;
+    if (lane >= active) return;
+    uint32_t xcc = 0;
+    if (PER_XCD) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+    }
+    uint32_t *t = tab + (size_t)xcc * (mask + 1u);
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t k = 0; k < per_lane; ++k)
+        __hip_atomic_fetch_add(&t[mix(g * 0x9E3779B97F4A7C15ull + k) & mask], 1u, __ATOMIC_RELAXED, SCOPE);
+}
+
+__global__ void k_sum(const uint32_t *tab, uint64_t n, unsigned long long *out) {
+    unsigned long long s = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) s += tab[i];
+    atomicAdd(out, s);
+}
+
+template <int SCOPE, bool PER_XCD>
+int run_scope(const char *name, uint32_t *tab8, uint32_t mask, uint64_t n_atom, unsigned long long *d_sum) {
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const uint32_t waves = 6144, per = (uint32_t)(n_atom / ((uint64_t)waves * 2));
+    for (int rep = 0; rep < 2; ++rep) {
+        CHK(hipMemset(tab8, 0, (size_t)8 * (mask + 1) * 4));
+        CHK(hipMemset(d_sum, 0, 8));
+        CHK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_atom_scope<SCOPE, PER_XCD>), dim3(waves / 4), dim3(256), 0, 0, tab8, mask, per, 2u);
+        CHK(hipEventRecord(e1, 0));
+        CHK(hipDeviceSynchronize());
+        float t;
+        CHK(hipEventElapsedTime(&t, e0, e1));
+        hipLaunchKernelGGL(k_sum, dim3(256), dim3(256), 0, 0, tab8, (uint64_t)8 * (mask + 1), d_sum);
+        unsigned long long h = 0;
+        CHK(hipMemcpy(&h, d_sum, 8, hipMemcpyDeviceToHost));
+        const unsigned long long want = (unsigned long long)waves * 2 * per;
+        printf("%-44s %.3f ms  %.1f G/s  sum %llu of %llu %s\n", name, t, want / t / 1e6, h, want, h == want ? "exact" : "LOST UPDATES");
+    }
+    return 0;
+}
+
 int main() {
     const uint64_t n_vec = (8600ull << 20) / 16;        // 8.6 GB each way
     uint4 *a, *b;
@@ -80,5 +126,14 @@ int main() {
                "copy + sparse atomics together: copy %.3f, atomics %.3f, both done after %.3f ms\n",
                tc, (unsigned long long)n_atom, ta_d, n_atom / ta_d / 1e6, ta_s, n_atom / ta_s / 1e6, tcopy2, tatom2, tb);
     }
+    uint32_t *tab8;
+    unsigned long long *d_sum;
+    CHK(hipMalloc(&tab8, (size_t)8 << 20));
+    CHK(hipMalloc(&d_sum, 8));
+    run_scope<__HIP_MEMORY_SCOPE_AGENT, false>("agent scope, one table", tab8, mask, n_atom, d_sum);
+    run_scope<__HIP_MEMORY_SCOPE_WORKGROUP, false>("workgroup scope, one table", tab8, mask, n_atom, d_sum);
+    run_scope<__HIP_MEMORY_SCOPE_WORKGROUP, true>("workgroup scope, one table per XCD", tab8, mask, n_atom, d_sum);
+    run_scope<__HIP_MEMORY_SCOPE_WAVEFRONT, true>("wavefront scope, one table per XCD", tab8, mask, n_atom, d_sum);
+    run_scope<__HIP_MEMORY_SCOPE_AGENT, true>("agent scope, one table per XCD", tab8, mask, n_atom, d_sum);
     return 0;
 }
