@@ -1460,16 +1460,18 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
 
 __device__ __forceinline__ void patch_sums(TileSum *sums, const TileSum *side, uint32_t *chg, uint32_t n_chg_words,
                                            uint32_t first, uint32_t stride) {
-    // summaries of the tiles the merge pass changed: side array -> live array
-    for (uint32_t w = first; w < n_chg_words; w += stride) {
-        uint32_t bits = chg[w];
-        if (!bits) continue;
-        chg[w] = 0;
-        while (bits) {
-            const uint32_t tile = w * 32u + (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1;
+    // summaries of the tiles the merge pass changed: side array -> live array.  A wave takes two words of the
+    // bitmap at a time, a lane per tile, so that the 16-byte copies of a wave are one contiguous kilobyte.
+    // (first / stride are thread numbers of a launch whose workgroups are whole waves)
+    const uint32_t lane = lane_id(), half = lane >> 5, bit = lane & 31u;
+    for (uint32_t w2 = first / kWave; 2u * w2 < n_chg_words; w2 += stride / kWave) {
+        const uint32_t w = 2u * w2 + half;
+        const uint32_t bits = w < n_chg_words ? chg[w] : 0u;
+        if ((bits >> bit) & 1u) {
+            const uint32_t tile = w * 32u + bit;
             reinterpret_cast<uint4 *>(sums)[tile] = reinterpret_cast<const uint4 *>(side)[tile];
         }
+        if (bit == 0u && bits) chg[w] = 0;
     }
 }
 
@@ -2806,6 +2808,24 @@ __global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, con
 // (see above).  Then the deltas of the surviving prefix are made exact for "only the prefix is
 // merged", and the argmax bounds of the dropped pairs are restored.
 constexpr int kValThreads = kBatchMax < 256 ? 256 : kBatchMax;
+// The pairs that only exist through touching matches, folded into maxp[] with the whole chip (the n x n block
+// of ADJ is mostly zeros; one thread per cell).  After k_adj_sums (adj_in / adj_out) and before k_validate.
+__global__ __launch_bounds__(256) void k_adj_max(const uint32_t *__restrict__ hdr_adj, BatchState *bs, const DevCtl *ctl) {
+    const uint32_t n = ctl->batch_n;
+    if (n < 2) return;
+    const uint32_t X0 = 256u + ctl->k_done;
+    const uint32_t i2 = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = i2 / kBatchMax, q = i2 % kBatchMax;
+    if (p >= n || q >= n) return;
+    const uint32_t w = hdr_adj[i2];
+    if (!w) return;
+    const uint32_t bp = bs->key[p] & 0xFFFFu, aq = bs->key[q] >> 16;
+    const unsigned long long xx = pack_best((int32_t)w, ((X0 + p) << 16) | (X0 + q));            // (X_p, X_q)
+    atomicMax(&bs->maxp[q > p ? q : p], xx);
+    atomicMax(&bs->maxp[q], pack_best((int32_t)bs->adj_in[q], (bp << 16) | (X0 + q)));          // (b_p, X_q), p not merged
+    atomicMax(&bs->maxp[p], pack_best((int32_t)bs->adj_out[p], ((X0 + p) << 16) | aq));         // (X_p, a_q), q not merged
+}
+
 __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m,
                                                           uint32_t *hdr_adj, uint32_t *LR) {
     static_assert(kBatchMax <= 1024, "one workgroup validates a batch, a thread per pair");
@@ -2819,30 +2839,9 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
     s_run[tid] = tid < n ? bs->maxp[tid] : 0ull;
     if (tid == 0) s_commit = n;
     __syncthreads();
-    // pairs that only exist through touching matches
-    // (n columns of the n rows that can hold something: n rounded up to a power of two keeps the index split cheap)
-    // (at least 64 columns per row, so a wave stays inside one row p: what goes to s_run[p] is reduced over the wave
-    //  first -- 64 LDS atomics on one address would serialise)
+    // (the pairs that only exist through touching matches were folded into maxp by k_adj_max)
     uint32_t nsh = 6;
     while ((1u << nsh) < n) ++nsh;
-    for (uint32_t i0 = 0; i0 < (n << nsh); i0 += blockDim.x) {
-        const uint32_t i2 = i0 + tid;
-        const uint32_t p = i2 >> nsh, q = i2 & ((1u << nsh) - 1u);
-        const bool in_range = p < n && q < n;
-        const uint32_t w = in_range ? hdr_adj[p * kBatchMax + q] : 0u;
-        unsigned long long to_p = 0;
-        if (w) {
-            const uint32_t bp = bs->key[p] & 0xFFFFu, aq = bs->key[q] >> 16;
-            const unsigned long long xx = pack_best((int32_t)w, ((X0 + p) << 16) | (X0 + q));            // (X_p, X_q)
-            if (q > p) atomicMax(&s_run[q], xx); else to_p = xx;
-            atomicMax(&s_run[q], pack_best((int32_t)bs->adj_in[q], (bp << 16) | (X0 + q)));              // (b_p, X_q), p not merged
-            const unsigned long long xa = pack_best((int32_t)bs->adj_out[p], ((X0 + p) << 16) | aq);     // (X_p, a_q), q not merged
-            to_p = xa > to_p ? xa : to_p;
-        }
-        to_p = wave_max_u64(to_p);
-        if (tid % kWave == 0 && to_p) atomicMax(&s_run[p], to_p);
-    }
-    __syncthreads();
     for (uint32_t d = 1; d < (uint32_t)kValThreads; d <<= 1) {        // inclusive prefix maximum
         const unsigned long long o = tid >= d ? s_run[tid - d] : 0ull;
         __syncthreads();
@@ -2893,6 +2892,8 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
     __syncthreads();
     const uint32_t commit = s_commit;
     // a match of a kept pair that touches a match of a dropped pair keeps its plain neighbour
+    // (nothing to do when the whole batch is kept, which is nearly always)
+    if (commit < n)
     for (uint32_t i2 = tid; i2 < (n << nsh); i2 += blockDim.x) {
         const uint32_t r = i2 >> nsh, q = i2 & ((1u << nsh) - 1u);
         if (q >= n) continue;
@@ -3752,6 +3753,7 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     if (blocks < 2) blocks = 2;
     hipLaunchKernelGGL(k_adj_sums, dim3(kBatchMax), dim3(kWave), 0, s, hdr_adj, bs, ctl);
     hipLaunchKernelGGL(k_delta_max, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, LR, bs, ctl);
+    hipLaunchKernelGGL(k_adj_max, dim3(kBatchMax * kBatchMax / 256), dim3(256), 0, s, hdr_adj, bs, ctl);
     hipLaunchKernelGGL(k_validate, dim3(1), dim3(kValThreads), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     if (t.cells) {
         uint32_t grid = ((id_upper + kApplyTile - 1) / kApplyTile) * (kBatchMax / kApplyTile);
