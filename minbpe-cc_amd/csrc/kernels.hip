@@ -1476,9 +1476,16 @@ __device__ __forceinline__ void patch_sums(TileSum *sums, const TileSum *side, u
 }
 
 __global__ void k_patch_sums(const unsigned long long *__restrict__ best_ptr, TileSum *sums, const TileSum *side,
-                             uint32_t *chg, uint32_t n_chg_words, DevCtl *ctl, int seq) {
+                             uint32_t *chg, uint32_t n_chg_words, DevCtl *ctl, int seq, uint32_t n_tiles) {
     if (seq) {
         if (ctl->batch_n == 0) return;
+        if (ctl->marks_all && ctl->fused && ctl->commit_n == ctl->batch_n) {
+            // a fused pass that is kept: the side array holds every tile's summary
+            const uint64_t n16 = (uint64_t)n_tiles;
+            for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+                reinterpret_cast<uint4 *>(sums)[i] = reinterpret_cast<const uint4 *>(side)[i];
+            return;
+        }
     } else if ((*best_ptr >> 32) == 0) {
         return;
     }
@@ -2507,7 +2514,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
-                                                 DeltaCache &dc, bool dc_on, uint32_t &wave_rm) {
+                                                 DeltaCache &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum) {
     constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
     // (an opaque copy of the lane id: the 64-bit lane masks below are cheaper to rebuild per tile than
@@ -2622,10 +2629,9 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
     } else {
         ns = make_uint4(old_x, old_y, (old_z & 0xFFFF0000u) | ((old_z & 0xFFFFu) - removed), 0u);
     }
-    if (lane == 0) {
-        reinterpret_cast<uint4 *>(sout)[tile] = ns;
-        atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
-    }
+    // (no tile mark: a fused pass writes every tile's summary to the side array, see DevCtl::marks_all)
+    if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
+    wrote_sum = true;
     return pack8(out);
 }
 
@@ -2664,6 +2670,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     if (dc_on) dc_init(dc);
     lut_build(lut, bs, n_keys, idmask - 1u);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->marks_all = 1;
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     uint32_t wave_rm = 0;        // uniform
     if (tile < n_tiles) {
@@ -2681,6 +2688,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
         TileIn t2 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 2ull * n_waves));
 
         uint4 outq = t0.q;
+        bool wrote_sum = false;          // uniform
         const uint32_t old_x = rlane(t0.smw, 4), old_y = rlane(t0.smw, 5), old_z = rlane(t0.smw, 6);
         if (DIAG == 4) {                 // timing-only build: copy
             asm volatile("" :: "v"(t0.smw));
@@ -2737,9 +2745,11 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             } else if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
                 outq = fused_tile_full<CHUNKED, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
-                                                wave_rm);
+                                                wave_rm, wrote_sum);
             }
         }
+        // every tile's summary goes to the side array (an unchanged tile's as it was): no tile marks needed
+        if (!wrote_sum && lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = make_uint4(old_x, old_y, old_z, 0u);
         MBPE_GLOBAL_AS char *obase =
             (MBPE_GLOBAL_AS char *)uniform_ptr(reinterpret_cast<uintptr_t>(dst) + (uint64_t)tile * (kWave * 16u));
         u32x4 oq; oq.x = outq.x; oq.y = outq.y; oq.z = outq.z; oq.w = outq.w;
@@ -3102,10 +3112,14 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
 // k_list_marked turns the bitmap into a dense list so that k_rewrite_marked can
 // walk it with the same prefetch ring as the streaming passes.
 __global__ void k_list_marked(const uint32_t *__restrict__ chg, uint32_t n_words, uint32_t *__restrict__ list,
-                              DevCtl *ctl) {
+                              DevCtl *ctl, uint32_t n_tiles) {
     if (ctl->batch_n < 2 || (ctl->fused && ctl->commit_n == ctl->batch_n)) return;
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bits = w < n_words ? chg[w] : 0u;
+    if (ctl->marks_all && w < n_words) {           // an abandoned fused pass: it marked nothing, every tile is a candidate
+        const uint32_t left = n_tiles - w * 32u;
+        bits = left >= 32u ? 0xFFFFFFFFu : (1u << left) - 1u;
+    }
     const uint32_t cnt = __popc(bits);
     const uint32_t incl = wave_incl_scan(cnt);
     const uint32_t total = __shfl(incl, kWave - 1, kWave);
@@ -3137,6 +3151,7 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
     __shared__ TTInfo ti;
     const uint32_t X0 = 256u + ctl->k_done;
     const uint32_t n_list = ctl->n_marked;
+    const bool marks_all = ctl->marks_all != 0u;
     lut_build(lut, bs, n_keys, idmask - 1u);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     const uint32_t lane = lane_id();
@@ -3203,8 +3218,11 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
         wave_rm += my_rm;
         if (__ballot(changed) != 0ull) {
             const uint4 ns = wave_summary(s);
-            if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
-        } else if (lane == 0) {
+            if (lane == 0) {
+                reinterpret_cast<uint4 *>(sout)[tile] = ns;
+                if (marks_all) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));    // (the fused pass set no marks)
+            }
+        } else if (lane == 0 && !marks_all) {
             atomicAnd(&chg[tile >> 5], ~(1u << (tile & 31u)));    // marked for a pair that was dropped
         }
 
@@ -3252,6 +3270,7 @@ __global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag, const BatchState
         else ctl->n_fused_dropped += 1;
     }
     ctl->fused = 0;
+    ctl->marks_all = 0;
     if (ctl->commit_n) ctl->size_hist[31 - __builtin_clz(ctl->commit_n) > 7 ? 7 : 31 - __builtin_clz(ctl->commit_n)] += 1;
     ctl->k_done += ctl->commit_n;
     ctl->batch_n = 0;
@@ -3624,7 +3643,7 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
     uint32_t blocks = (n_words + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_patch_sums, dim3(blocks), dim3(256), 0, s, best, sums, side, chg, n_words, ctl, seq);
+    hipLaunchKernelGGL(k_patch_sums, dim3(blocks), dim3(256), 0, s, best, sums, side, chg, n_words, ctl, seq, n_tiles);
 }
 
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
@@ -3771,7 +3790,7 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok, uint16_t *tok1, const T
                            const uint32_t *run_in) {
     if (!n_tiles) return;
     const uint32_t n_words = (n_tiles + 31u) / 32u;
-    hipLaunchKernelGGL(k_list_marked, dim3((n_words + 255) / 256), dim3(256), 0, s, chg, n_words, list, ctl);
+    hipLaunchKernelGGL(k_list_marked, dim3((n_words + 255) / 256), dim3(256), 0, s, chg, n_words, list, ctl, n_tiles);
     static const int occ_c = resident_blocks(k_rewrite_marked<true, false>, kLutThreads),
                      occ_b = resident_blocks(k_rewrite_marked<false, false>, kLutThreads);
     const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kLutThreads);

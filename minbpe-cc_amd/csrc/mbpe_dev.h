@@ -123,6 +123,8 @@ struct DevCtl {
     uint32_t skip_failed;       // set by k_validate for k_seq_finish
     uint32_t skip_red_q16;      // what passed-over candidates lost lately, as a fraction of their count (low estimate)
     unsigned long long n_sel_blocks;   // blocks read by the gathers (statistics)
+    uint32_t marks_all;         // the fused pass of this sequence wrote EVERY tile's summary to the side array and set no
+                                //   tile marks (its tiles nearly all change): "every tile is marked"
 
 };
 
