@@ -1120,6 +1120,7 @@ __global__ void k_table_init(const uint32_t *__restrict__ bp, PairTable t, DevCt
     if (i >= 65536u) return;
     uint32_t c = bp[i];
     if (!c) return;
+    if (c >= kPresent) { atomicOr(&ctl->err, kErrCountRange); return; }     // (int counts in the reference too: PairCount.h:188)
     uint32_t key = ((i >> 8) << 16) | (i & 0xFFu);
     table_add(t, ctl, key, (int32_t)c, true);
 }
@@ -3587,7 +3588,7 @@ void launch_first_tiebreak(hipStream_t s, PairTable t, const DevCtl *ctl, unsign
 void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileSum *sin, TileSum *sout, uint32_t n_tiles,
                   uint32_t *chg, const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *LR,
                   DevCtl *ctl, uint32_t *m_adj, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus,
-                  int seq, unsigned long long *run_part, uint32_t *run_in, const BatchState *bs) {
+                  int seq, unsigned long long *run_part, uint32_t *run_in, const BatchState *bs, int hot_possible) {
     if (!n_tiles) return;
     {   // runs of t before every tile, for a (t,t) pair (the kernels return at once for any other pair)
         const uint32_t n_chunks = (n_tiles + kRunChunk - 1) / kRunChunk;
@@ -3615,11 +3616,13 @@ void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileS
     if (endbit) {
         hipLaunchKernelGGL((k_merge<true, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq, run_in);
+        if (hot_possible)
         hipLaunchKernelGGL((k_merge<true, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq, run_in);
     } else {
         hipLaunchKernelGGL((k_merge<false, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq, run_in);
+        if (hot_possible)
         hipLaunchKernelGGL((k_merge<false, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq, run_in);
     }
@@ -3669,7 +3672,7 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
                         uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in) {
+                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible) {
     if (!n_tiles) return;
     static const int occ_c = resident_blocks(k_fused_batch<true, false, false, 0>, kLutThreads),
                      occ_b = resident_blocks(k_fused_batch<false, false, false, 0>, kLutThreads);
@@ -3695,8 +3698,10 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
         hipLaunchKernelGGL((k_fused_batch<true, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        if (hot_possible)
         hipLaunchKernelGGL((k_fused_batch<true, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        if (hot_possible)
         hipLaunchKernelGGL((k_fused_batch<true, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
     } else {
@@ -3704,8 +3709,10 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
         hipLaunchKernelGGL((k_fused_batch<false, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        if (hot_possible)
         hipLaunchKernelGGL((k_fused_batch<false, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        if (hot_possible)
         hipLaunchKernelGGL((k_fused_batch<false, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
     }
@@ -3714,7 +3721,7 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
 void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1, const TileSum *sums, uint32_t n_tiles,
                        uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
                        const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                       int n_cus, const uint32_t *run_in) {
+                       int n_cus, const uint32_t *run_in, int hot_possible) {
     if (!n_tiles) return;
     static const int occ_c = resident_blocks(k_scan_batch<true, false, false, 0>, kLutThreads),
                      occ_b = resident_blocks(k_scan_batch<false, false, false, 0>, kLutThreads);
@@ -3747,8 +3754,10 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
                            left_edge, right_edge, run_in);
         hipLaunchKernelGGL((k_scan_batch<true, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge, run_in);
+        if (hot_possible)
         hipLaunchKernelGGL((k_scan_batch<true, true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge, run_in);
+        if (hot_possible)
         hipLaunchKernelGGL((k_scan_batch<true, true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge, run_in);
     } else {
@@ -3756,8 +3765,10 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
                            left_edge, right_edge, run_in);
         hipLaunchKernelGGL((k_scan_batch<false, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge, run_in);
+        if (hot_possible)
         hipLaunchKernelGGL((k_scan_batch<false, true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge, run_in);
+        if (hot_possible)
         hipLaunchKernelGGL((k_scan_batch<false, true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
                            left_edge, right_edge, run_in);
     }

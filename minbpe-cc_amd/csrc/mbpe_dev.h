@@ -184,6 +184,7 @@ inline uint32_t batch_header_words() { return (uint32_t)(kBatchMax + kBatchMax *
 constexpr uint32_t kErrTableFull   = 1u;
 constexpr uint32_t kErrNegCount    = 2u;
 constexpr uint32_t kErrMissingPair = 4u;
+constexpr uint32_t kErrCountRange  = 8u;   // a pair count does not fit 31 bits (the table keeps a "present" flag in bit 31)
 
 // packed argmax word: (count << 32) | ~key  -- larger is better:
 // count descending, then key ascending == (first, second) ascending,
@@ -239,7 +240,8 @@ void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileS
                   const RankEdge *left_edge, const RankEdge *right_edge, int n_cus, int seq,
                   unsigned long long *run_part /* tile_scan_scratch(n_tiles) entries */,
                   uint32_t *run_in /* n_tiles entries: run of t before every tile, for (t,t) pairs */,
-                  const BatchState *bs /* seq != 0: a batch may hold a (t,t) member */);
+                  const BatchState *bs /* seq != 0: a batch may hold a (t,t) member */,
+                  int hot_possible = 1 /* 0: the frequent-pair (delta cache) instantiations cannot be needed: not launched */);
 // seq != 0: the kernel runs inside a batch sequence: it reads the merge index
 // from ctl->k_done and returns at once unless the selected batch has one pair;
 // tok / tok_other are then token buffers 0 / 1 and ctl->cur picks the live one
@@ -265,12 +267,12 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 void launch_scan_batch(hipStream_t s, const uint16_t *tok0, const uint16_t *tok1, const TileSum *sums,
                        uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                        uint32_t *LR, const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge,
-                       uint32_t endbit, int n_cus, const uint32_t *run_in);
+                       uint32_t endbit, int n_cus, const uint32_t *run_in, int hot_possible = 1);
 // large batch (ctl->fused): count the deltas and write the merged stream to the other buffer
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
                         uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in);
+                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible = 1);
 // k_delta_max + k_validate + k_apply_batch
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                          uint32_t *LR, uint32_t id_upper);

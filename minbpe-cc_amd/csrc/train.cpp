@@ -199,6 +199,7 @@ struct mbpe_ctx {
     int64_t opt_sel_cap = kSelCap;      // candidate-list capacity (tests lower it to force the overflow path)
     int64_t opt_threshold_select = 1;   // 0: always select with the bound-walking kernel
     int64_t opt_dense_table = -1;   // -1 auto / 1: dense pair table when vocab <= 32,768; 0: always hashed
+    int hot_possible = 1;           // may a batch of the next group of sequences hold a "frequent" pair (kernels' dc_wanted)?
     int64_t opt_first = 0;          // 1: `first` tie-break (insertion order, PairCount.h:65-74) instead of lexical
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
@@ -273,7 +274,8 @@ int sync_ctl(mbpe_ctx *c) {
 #endif
     if (c->h_ctl.err) {
         char buf[160];
-        snprintf(buf, sizeof(buf), "device error flags 0x%x (1=pair table full, 2=negative count, 4=missing pair)",
+        snprintf(buf, sizeof(buf), "device error flags 0x%x (1=pair table full, 2=negative count, 4=missing pair, "
+                                   "8=a pair occurs 2^31 times or more)",
                  c->h_ctl.err);
         mbpe_host::set_last_error(buf);
         return MBPE_ERR_OVERFLOW;
@@ -743,6 +745,17 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     return MBPE_OK;
 }
 
+// The stream kernels exist in a plain and a HOT instantiation (LDS cache for the count updates of a frequent
+// pair) and the device decides which one works: top_count * 8192 >= n_live (dc_wanted in kernels.hip).  The
+// maximal count never rises, and n_live falls by at most one count per merge, so for the next `merges` merges
+// HOT stays impossible while top * 8192 < (n_live - merges * top) * ranks: then it is not even launched.
+static void update_hot_possible(mbpe_ctx *c, unsigned long long top_count, uint64_t merges) {
+    if (c->comm_external) { c->hot_possible = 1; return; }     // (the caller drives the sequences one by one)
+    const unsigned long long live = c->h_ctl.n_live;
+    const unsigned long long eaten = merges * top_count;
+    c->hot_possible = !(live > eaten && top_count * 8192ull < (live - eaten) * (unsigned long long)std::max(1, c->n_ranks));
+}
+
 static int begin_finish(mbpe_ctx *c) {
     const uint32_t endbit = c->chunked ? kEndBit : 0;
     if (is_multi(c)) {
@@ -763,6 +776,7 @@ static int begin_finish(mbpe_ctx *c) {
     unsigned long long b0 = 0;
     HIPCHK(hipMemcpy(&b0, c->best, 8, hipMemcpyDeviceToHost));
     c->exhausted = (b0 == 0);   // empty table: the reference loop breaks at once (Tokenizer.h:586-588)
+    update_hot_possible(c, b0 >> 32, (uint64_t)std::max<int64_t>(c->opt_batch, 1) * kBatchMax);
     c->begun = true;
     c->stats.ms_steps = 0;
     return MBPE_OK;
@@ -820,12 +834,12 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     // (the live token buffer is ctl->cur: a fused pass flips it without the host knowing)
     launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
-                 multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1, c->offsets + c->n_tiles, c->run_in, c->bs);
+                 multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1, c->offsets + c->n_tiles, c->run_in, c->bs, c->hot_possible);
     launch_scan_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
-                      c->ctl, le, re, endbit, c->n_cus, c->run_in);
+                      c->ctl, le, re, endbit, c->n_cus, c->run_in, c->hot_possible);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev_f[2 * ev_slot], c->stream);
     launch_fused_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->bs, c->hdr_adj, c->LR,
-                       c->ctl, le, re, endbit, c->n_cus, c->hdr_m, c->run_in);
+                       c->ctl, le, re, endbit, c->n_cus, c->hdr_m, c->run_in, c->hot_possible);
     if (ev_slot >= 0) {
         (void)hipEventRecord(c->kev_f[2 * ev_slot + 1], c->stream);
         (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
@@ -987,6 +1001,11 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
         }
         const uint32_t before = c->k;
         c->k = c->h_ctl.k_done;
+        if (c->k) {             // the count of the latest merge bounds every later one
+            unsigned long long last = 0;
+            HIPCHK(hipMemcpy(&last, c->best + (c->k - 1), 8, hipMemcpyDeviceToHost));
+            update_hot_possible(c, last >> 32, (uint64_t)seqs_per_sync(c) * kBatchMax);
+        }
         rc = after_batch(c);
         if (rc != MBPE_OK) return rc;
         if (c->k == before) break;      // nothing left to merge

@@ -169,6 +169,19 @@ def test_pair_count_rollback_paths(tr):
     assert int(got[(7 << 8) | 7]) == len(data) - 1 and int(got.sum()) == len(data) - 1
 
 
+def test_pair_count_beyond_31_bits_is_reported(tr):
+    # the table keeps "ever inserted" in bit 31 of a cell, and the reference counts in int (PairCount.h:188): a
+    # pair that occurs 2^31 times or more is an error, not a silently corrupted table
+    n = (1 << 31) + 4096
+    data = np.full(n, 7, dtype=np.uint8)
+    tr.load_corpus(data)
+    with pytest.raises(mbpe.MbpeError) as e:
+        tr.train_begin(300)
+    assert e.value.code == mbpe.ERR_OVERFLOW
+    tr.load_corpus(b"abab")                      # the context stays usable
+    assert tr.train_lexical(b"abab", 258)[0].tolist() == [[97, 98], [256, 256]]
+
+
 def test_train_kat_small_and_aaaa(tr):
     m, c, _ = tr.train_lexical(read_data("small.txt"), 275)
     want = [[98, 99], [100, 101], [256, 257], [258, 258], [97, 259], [258, 10], [260, 261]] + [[97, 98]] * 12
