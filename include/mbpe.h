@@ -18,8 +18,11 @@
  *
  * Token ids: the device stream holds 16-bit slots.  vocab_size may be at most
  * MBPE_MAX_VOCAB_BASIC for a single-chunk corpus and MBPE_MAX_VOCAB_CHUNKED
- * when chunk boundaries are present (one slot bit marks "last token of its
- * chunk").  Larger requests return MBPE_ERR_VOCAB.
+ * when chunk boundaries are present.  Up to MBPE_MAX_VOCAB_ENDBIT a chunked
+ * stream marks "last token of its chunk" with one slot bit; beyond that it
+ * keeps a barrier slot after every chunk instead (one more slot per chunk,
+ * ids use all 16 bits).  Larger requests return MBPE_ERR_VOCAB; the
+ * reference's Token is a uint32_t (Tokenizer.h:37).
  */
 #ifndef MBPE_H
 #define MBPE_H
@@ -33,7 +36,9 @@ extern "C" {
 #define MBPE_API __attribute__((visibility("default")))
 
 #define MBPE_MAX_VOCAB_BASIC   65534u
-#define MBPE_MAX_VOCAB_CHUNKED 32766u
+#define MBPE_MAX_VOCAB_ENDBIT  32766u
+#define MBPE_MAX_VOCAB_CHUNKED 65518u
+#define MBPE_NO_BARRIER 0xFFFFFFFFu
 
 typedef enum {
     MBPE_NEED_EXCHANGE =  1,  /* external-transport mode only: reduce the exchange buffer, then
@@ -207,10 +212,11 @@ MBPE_API int mbpe_get_stream(mbpe_ctx *ctx, uint32_t *tokens_out, uint8_t *chunk
 
 /* Device view of the slot stream, for checks that run on the device (tests, bench.py): n_slots
  * slots of slot_bits bits each in device memory, valid until the next training call.  A slot equal
- * to the all-ones value is a hole; end_bit (0 for a one-chunk corpus) is the slot bit that marks the
- * last token of a chunk, the token id is the slot without it. */
+ * to the all-ones value is a hole; end_bit (0 when there is none) is the slot bit that marks the
+ * last token of a chunk, the token id is the slot without it; barrier (MBPE_NO_BARRIER when there
+ * is none) is the slot value that stands after the last token of every chunk and is no token. */
 MBPE_API int mbpe_stream_device(mbpe_ctx *ctx, const void **slots_out, uint64_t *n_slots_out,
-                                uint32_t *slot_bits_out, uint32_t *end_bit_out);
+                                uint32_t *slot_bits_out, uint32_t *end_bit_out, uint32_t *barrier_out);
 
 /* Device view of the dense pair table (vocab_size <= 32,768 unless "dense_table" is 0; MBPE_ERR_STATE
  * for the hashed layout): 1 << (2 * vshift) u32 cells, cell of (a, b) at
@@ -245,6 +251,8 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *                   (single-merge mode)
  *   "force_exchange" 1 = take the multi-rank path (rank edges, exchange) even
  *                   with a single rank (tests the RCCL binding on one GPU)
+ *   "chunk_barrier" chunk ends of a chunked corpus as barrier slots: -1 (default) when vocab_size
+ *                   exceeds MBPE_MAX_VOCAB_ENDBIT, 1 always, 0 never; read by mbpe_train_begin
  *   "conflict_resolution" 1 = lexical tie-break (default), 0 = first (see mbpe_train); before
  *                   mbpe_train_begin only
  *   "time_kernels"  1 = bracket every merge kernel with HIP events on the

@@ -581,7 +581,56 @@ __global__ void k_widen(const uint8_t *__restrict__ text, uint64_t n, const uint
     }
 }
 
+// Barrier layout (chunked corpora whose ids need all 16 bits): byte i goes to slot 2i, slot 2i+1 holds the
+// barrier when byte i ends its chunk and a hole otherwise -- 256 bytes per tile, whatever the chunk lengths.
+// The host squeezes the holes out right afterwards (the ordinary compaction).
+__global__ void k_widen_barrier(const uint8_t *__restrict__ text, uint64_t n, const uint8_t *__restrict__ endmask,
+                                uint16_t *__restrict__ tok, uint64_t n_slots) {
+    uint64_t vec = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;          // 8 bytes -> 16 slots
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_vec = n_slots / 16;
+    for (; vec < n_vec; vec += stride) {
+        const uint64_t byte0 = vec * 8;
+        uint32_t w[2] = {0, 0};
+        uint32_t ends = 0;
+        if (byte0 + 8 <= n) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(text + byte0);
+            w[0] = q.x; w[1] = q.y;
+        } else {
+            for (uint64_t i = byte0; i < n; ++i) w[(i - byte0) >> 2] |= (uint32_t)text[i] << (8 * ((i - byte0) & 3));
+        }
+        if (byte0 < n) ends = endmask[vec];
+        uint32_t o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t t = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            uint32_t e = ((ends >> i) & 1u) ? kBarrier : kHole;
+            if (byte0 + i >= n) { t = kHole; e = kHole; }
+            o[i] = t | (e << 16);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(tok + vec * 16);
+        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+
 // ---- wave-level tile helpers ---------------------------------------------------
+
+// How the stream kernels know where a chunk ends (template parameter MODE):
+//   0  one chunk: every two neighbouring live tokens form a pair
+//   1  bit 15 of the chunk's last token (ids below 0x7FFF)
+//   2  a BARRIER slot after the chunk's last token (kBarrier, see mbpe_dev.h): a live token that belongs to no
+//      pair, so ids use the full 16 bits.  It is never a member of a batch pair, so no match can contain or
+//      span it; the only places that have to know are the ones that COUNT a neighbour pair.
+// left_open(p1): a pair (p1, self) exists for the live token `self`; right_open(self, n1): a pair (self, n1) exists.
+template <int MODE>
+__device__ __forceinline__ bool left_open(uint32_t p1) {
+    return p1 != kHole && (MODE == 1 ? !(p1 & kEndBit) : MODE == 2 ? p1 != kBarrier : true);
+}
+template <int MODE>
+__device__ __forceinline__ bool right_open(uint32_t self, uint32_t n1) {
+    return n1 != kHole && (MODE == 1 ? !(self & kEndBit) : MODE == 2 ? n1 != kBarrier : true);
+}
 
 __device__ __forceinline__ void unpack8(const uint4 &q, uint32_t s[8]) {
     s[0] = q.x & 0xFFFFu; s[1] = q.x >> 16;
@@ -1035,14 +1084,14 @@ __global__ __launch_bounds__(256) void k_first_gather(PairTable t, const DevCtl 
     if (lane == 0 && found) atomicAdd(&fs->n_tie, found);
 }
 
-template <bool CHUNKED>
+template <int MODE>
 __global__ __launch_bounds__(kMergeThreads) void k_first_pos(const uint16_t *__restrict__ tok,
                                                              const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                              PairTable t,
                                                              const unsigned long long *__restrict__ best_ptr,
                                                              FirstState *fs) {
-    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
-    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     __shared__ uint32_t bm[kFirstBitmapWords];
     if (fs->n_tie <= 1) return;                           // a unique maximum: position does not matter
     const uint32_t M = (uint32_t)(*best_ptr >> 32);
@@ -1080,7 +1129,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_first_pos(const uint16_t *__r
         for (int j = 7; j >= 0; --j) {
             const uint32_t self = s[j];
             if (self == kHole) continue;
-            if (nx != kHole && !(self & endbit)) {        // a pair starts here (Tokenizer.h:135-144)
+            if (right_open<MODE>(self, nx) && (MODE != 2 || self != kBarrier)) {   // a pair starts here (Tokenizer.h:135-144)
                 const uint32_t key = ((self & idmask) << 16) | (nx & idmask);
                 const uint32_t hb = first_hash(key);
                 if ((bm[hb >> 5] >> (hb & 31u)) & 1u) {
@@ -1212,15 +1261,15 @@ __device__ __forceinline__ TileIn tile_issue(const uint16_t *tok, __amdgpu_buffe
 // neighbours two deep on both sides, decisions, count deltas, in-place
 // rewrite and the tile's new summary.  Returns true when the summary was
 // written (the tile changed).
-template <bool CHUNKED>
+template <int MODE>
 __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *sin, TileSum *sout, uint32_t *chg,
                                                 uint32_t n_tiles,
                                              uint32_t tile, uint32_t s[8], const Halo h, uint32_t a, uint32_t b,
                                              uint32_t X, uint32_t *LR, DeltaCache &dc, bool dc_on,
                                              const uint32_t *run_in,
                                              uint32_t &wave_m, uint32_t &wave_adj, uint32_t &wave_rm) {
-    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
-    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     const uint32_t lane = lane_id();
     const bool same = a == b;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1321,14 +1370,14 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
         if (amatch) {
             nv = X | (n1 & endbit);
             ++my_m;
-            if (p1 != kHole && !(p1 & endbit)) {
+            if (left_open<MODE>(p1)) {
                 if (prev_adjacent) ++my_adj;
                 else dc_add(dc, dc_on, LR, lr_idx(p1, 0, 0), 1u);
             }
         } else if (bmatch) {
             nv = kHole;
             ++my_rm;
-            if (!(self & endbit) && n1 != kHole) {
+            if (right_open<MODE>(self, n1)) {
                 const bool next_adjacent = (n1 == a) && ((n2 & idmask) == b);
                 if (!next_adjacent) dc_add(dc, dc_on, LR, lr_idx(n1 & idmask, 0, 1), 1u);
             }
@@ -1349,7 +1398,7 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
     return true;
 }
 
-template <bool CHUNKED, bool HOT, int DIAG>
+template <int MODE, bool HOT, int DIAG>
 __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_t *tok1,
                                                          const TileSum *__restrict__ sin,
                                                          TileSum *__restrict__ sout, uint32_t n_tiles,
@@ -1359,7 +1408,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
                                                          uint32_t *m_adj, const RankEdge *le,
                                                          const RankEdge *re, int seq,
                                                          const uint32_t *__restrict__ run_in) {
-    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     __shared__ DeltaCache dc;
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
@@ -1428,14 +1477,14 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
             uint32_t acc = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                const uint32_t u = (CHUNKED ? (c & idmask) : c) ^ b;
+                const uint32_t u = (MODE == 1 ? (c & idmask) : c) ^ b;
                 const uint32_t tu = (s[j] ^ a) + u;      // 0 <=> s[j] == a and id(next live) == b
                 acc = tu < acc ? tu : acc;
                 c = s[j] != kHole ? s[j] : c;
             }
             bool work = __ballot(acc == 0u) != 0ull || h.p1 == a;
             if (DIAG == 2) { asm volatile("" :: "v"(acc)); work = false; }
-            if (work) merge_tile_full<CHUNKED>(tok, sin, sout, chg, n_tiles, tile, s, h, a, b, X, LR, dc, dc_on, run_in,
+            if (work) merge_tile_full<MODE>(tok, sin, sout, chg, n_tiles, tile, s, h, a, b, X, LR, dc, dc_on, run_in,
                                                    wave_m, wave_adj, wave_rm);
         }
 
@@ -2169,10 +2218,10 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
 // run"), joined from lane to lane, started from the run that ends the previous tile (run_in, from
 // k_run_final).  The neighbour tokens taken from the summaries are renamed alike.  A token that ends
 // its chunk can be the second token of a match but continues no run.
-template <bool CHUNKED>
+template <int MODE>
 __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &ti, uint32_t rb_small) {
-    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
-    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     const uint32_t lane = lane_id();
     auto stand_in = [&](uint32_t v) -> uint32_t {      // v: a live token at an odd position of its run
         const uint32_t id = v & idmask;
@@ -2262,10 +2311,10 @@ __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &
 // alone -- which is nearly always: two per tile of random bytes repeat their predecessor, one in sixteen of
 // those is one of the batch's handful of (t,t) tokens.  Conservative (chunk ends are ignored).
 // nxt[j]: the live token after slot j (kHole: none); tile_first: the tile's first live token.
-template <bool CHUNKED>
+template <int MODE>
 __device__ __forceinline__ bool tt_needed(const uint32_t s[8], const uint32_t nxt[8], const Halo &h,
                                           uint32_t tile_first, const TTInfo &ti) {
-    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     auto member = [&](uint32_t v) -> bool {
         const uint32_t id = v & idmask;
         return (ti.map[id & (kTTSlots - 1u)] & 0xFFFFu) == id;
@@ -2345,12 +2394,12 @@ __device__ __forceinline__ Neigh tile_neighbours(const uint32_t s[8], const Halo
 // both a first and a second element), so "this token is the second of a match"
 // is simply "the previous live token started a match": one membership test per
 // live slot, everything else only where a match is.
-template <bool CHUNKED, int DIAG = 0>
+template <int MODE, int DIAG = 0>
 __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, const uint32_t s[8], const Halo h,
                                                const BatchLut &lut, uint32_t n_keys, uint32_t *hdr_adj,
                                                uint32_t *LR, DeltaCache &dc, bool dc_on, bool tt_on, TTInfo &ti) {
-    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
-    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     const Neigh nb = tile_neighbours(s, h);
     if (DIAG == 4) {
         asm volatile("" :: "v"(nb.p1_in), "v"(nb.p2_in));
@@ -2372,7 +2421,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
         bool is_a = false;
         if (a1) {                                        // second token of a match of pair (p1, self)
             any = true;
-            if (!(self & endbit) && n1 != kHole && !pair_test(lut, n1, n2 & idmask)) {
+            if (right_open<MODE>(self, n1) && !pair_test(lut, n1, n2 & idmask)) {
                 const int jb = lut_index(lut, p1, self & idmask);
                 if (DIAG != 3) dc_add(dc, dc_on, LR, lr_idx(n1 & idmask, (uint32_t)jb, 1), 1u);
                 else asm volatile("" :: "v"(jb));
@@ -2383,7 +2432,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
             const int ja = lut_index(lut, self, n1 & idmask);
             if (tt_on && (n1 & idmask) >= idmask - (uint32_t)kTTMax)      // a match of a (t,t) member: count it
                 atomicAdd(&ti.cnt[idmask - 1u - (n1 & idmask)], 1u);
-            if (p1 != kHole && !(p1 & endbit)) {
+            if (left_open<MODE>(p1)) {
                 if (p2 != kHole && pair_test(lut, p2, p1)) {               // two matches touch
                     const int jp = lut_index(lut, p2, p1);
                     atomicAdd(&hdr_adj[jp * kBatchMax + ja], 1u);
@@ -2399,7 +2448,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
     if (__ballot(any) != 0ull && lane_id() == 0) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
 }
 
-template <bool CHUNKED, bool HOT, bool TT, int DIAG = 0>
+template <int MODE, bool HOT, bool TT, int DIAG = 0>
 __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0, const uint16_t *tok1,
                                                               const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                               uint32_t *__restrict__ chg, const BatchState *bs,
@@ -2407,7 +2456,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
                                                               const DevCtl *ctl, const RankEdge *le,
                                                               const RankEdge *re,
                                                               const uint32_t *__restrict__ run_in) {
-    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     __shared__ BatchLut lut;
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kLutThreads / kWave;
@@ -2454,7 +2503,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             } else {
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
-            if (TT) tt_rename<CHUNKED>(s, h, ti, run_in[tile]);
+            if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);
             // first live token of the lanes after this one (exact), then the candidate
             // test: some slot and its next live token form one of the batch pairs
             uint32_t lf = kHole;
@@ -2467,7 +2516,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             uint32_t miss = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                const uint32_t d = pair_miss(lut, s[j], CHUNKED ? c & idmask : c);    // (ids are 16-bit: no mask needed)
+                const uint32_t d = pair_miss(lut, s[j], MODE == 1 ? c & idmask : c);    // (ids are 16-bit: no mask needed)
                 miss = d < miss ? d : miss;
                 c = s[j] != kHole ? s[j] : c;
             }
@@ -2476,7 +2525,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             bool work = __ballot(cand) != 0ull || pair_test(lut, h.p1, tile_first & idmask);
             if (DIAG == 2) { asm volatile("" :: "v"((uint32_t)cand)); work = false; }
-            if (work) scan_tile_full<CHUNKED, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, dc, dc_on, TT, ti);
+            if (work) scan_tile_full<MODE, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, dc, dc_on, TT, ti);
         }
         if (!v1) break;
         tile += n_waves;
@@ -2508,7 +2557,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
 // live.  Everything else (pair index, neighbours, deltas) is only done where a
 // match is.
 
-template <bool CHUNKED, int DIAG = 0>
+template <int MODE, int DIAG = 0>
 __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on, TTInfo &ti,
                                                  const uint32_t s[8], const uint32_t cj[8],
                                                  uint32_t Am, unsigned long long m_live, uint32_t c_init, const Halo h,
@@ -2516,8 +2565,8 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
                                                  DeltaCache &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum) {
-    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
-    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     // (an opaque copy of the lane id: the 64-bit lane masks below are cheaper to rebuild per tile than
     //  to keep in registers across the streaming loop, where the compiler would spill them)
     uint32_t lane = lane_id();
@@ -2589,7 +2638,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
             }
             // first token of a match: (p1, a) -> (p1, X); second token: (b, n1) -> (X, n1)
             const uint32_t nb = is_a ? p1 : cj[j];                       // the neighbour the match loses
-            const bool counted = is_a ? (p1 != kHole && !(p1 & endbit)) : (!(self & endbit) && cj[j] != kHole);
+            const bool counted = is_a ? left_open<MODE>(p1) : right_open<MODE>(self, cj[j]);
             nv = is_a ? (X0 + ja) | (cj[j] & endbit) : kHole;
             if (counted && DIAG != 2) {
                 if (is_a && ((touch >> j) & 1u)) {        // ... (a', b') (a, b): (b', a) -> (X', X)
@@ -2644,7 +2693,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
 #ifndef MBPE_FUSED_WAVES
 #define MBPE_FUSED_WAVES 4
 #endif
-template <bool CHUNKED, bool HOT, bool TT, int DIAG = 0>
+template <int MODE, bool HOT, bool TT, int DIAG = 0>
 __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) void k_fused_batch(uint16_t *tok0, uint16_t *tok1,
                                                                const TileSum *__restrict__ sin,
                                                                TileSum *__restrict__ sout, uint32_t n_tiles,
@@ -2652,7 +2701,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                                                                uint32_t *hdr_adj, uint32_t *LR, DevCtl *ctl,
                                                                const RankEdge *le, const RankEdge *re,
                                                                uint32_t *hdr_m, const uint32_t *__restrict__ run_in) {
-    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     __shared__ BatchLut lut;
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kLutThreads / kWave;
@@ -2730,21 +2779,21 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                     cj[j] = c;
                     c = s[j] != kHole ? s[j] : c;
                 }
-                if (!TT || rep || DIAG == 5 || !tt_needed<CHUNKED>(s, cj, h, tile_first, ti)) break;
-                tt_rename<CHUNKED>(s, h, ti, run_in[tile]);
+                if (!TT || rep || DIAG == 5 || !tt_needed<MODE>(s, cj, h, tile_first, ti)) break;
+                tt_rename<MODE>(s, h, ti, run_in[tile]);
                 renamed = true;
             }
             uint32_t Am = 0;             // bit j: slot j starts a match
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                const bool hit = pair_hit(lut, s[j], CHUNKED ? cj[j] & idmask : cj[j]);     // (ids are 16-bit: no mask needed)
+                const bool hit = pair_hit(lut, s[j], MODE == 1 ? cj[j] & idmask : cj[j]);     // (ids are 16-bit: no mask needed)
                 Am = Am + Am + (hit ? 1u : 0u);         // one add-with-carry, the carry being the compare mask
             }
             const bool any = Am != 0u;
             if (DIAG == 3 || DIAG == 5) {    // timing-only build: membership tests, no merge
                 asm volatile("" :: "v"(Am));
             } else if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
-                outq = fused_tile_full<CHUNKED, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, m_live, c_init, h, tile_first,
+                outq = fused_tile_full<MODE, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
                                                 wave_rm, wrote_sum);
             }
@@ -3133,7 +3182,7 @@ __global__ void k_list_marked(const uint32_t *__restrict__ chg, uint32_t n_words
     }
 }
 
-template <bool CHUNKED, bool TT>
+template <int MODE, bool TT>
 __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, uint16_t *tok1,
                                                                   const TileSum *__restrict__ sin,
                                                                   TileSum *__restrict__ sout, uint32_t n_tiles,
@@ -3142,8 +3191,8 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
                                                                   const BatchState *bs, DevCtl *ctl,
                                                                   const RankEdge *le, const RankEdge *re,
                                                                   const uint32_t *__restrict__ run_in) {
-    constexpr uint32_t idmask = CHUNKED ? 0x7FFFu : 0xFFFFu;
-    constexpr uint32_t endbit = CHUNKED ? kEndBit : 0u;
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     __shared__ BatchLut lut;
     if (ctl->batch_n < 2 || (ctl->fused && ctl->commit_n == ctl->batch_n)) return;
     uint16_t *tok = ctl->cur ? tok1 : tok0;
@@ -3186,7 +3235,7 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
         } else {
             h = halo_slow(sin, n_tiles, tile, le, re);
         }
-        if (TT) tt_rename<CHUNKED>(s, h, ti, run_in[tile]);
+        if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);
         const Neigh nb = tile_neighbours(s, h);
         bool changed = false, a1 = false, first = true;
         uint32_t p1 = nb.p1_in, my_rm = 0;
@@ -3471,7 +3520,8 @@ __global__ void k_boundary_pairs(uint32_t *bp, const uint32_t *hdr, int n_ranks,
     for (int j = 0; j < n_ranks; ++j) {
         const RankEdge e = all[j];
         if (e.head0 == kHole) continue;            // empty shard
-        if (prev_tail != kHole && !(prev_tail & endbit))
+        const bool ends = endbit == kBarrier ? prev_tail == kBarrier : (prev_tail & endbit) != 0u;
+        if (prev_tail != kHole && !ends)
             bp[((prev_tail & 0xFFu) << 8) | (e.head0 & 0xFFu)] += 1;
         prev_tail = e.tail0;
     }
@@ -3508,6 +3558,16 @@ inline int tile_grid(uint32_t n_tiles, int n_cus, int blocks_per_cu = 8, int thr
 
 // ---- launchers ---------------------------------------------------------------------------
 
+// The launchers take the chunk-end convention as `endbit`: 0 (one chunk), kEndBit (flag in the slot) or kBarrier
+// (barrier slots); the kernels take it as the template parameter MODE = 0 / 1 / 2.
+static inline int slot_mode(uint32_t endbit) { return endbit == kEndBit ? 1 : endbit == kBarrier ? 2 : 0; }
+#define MBPE_BY_MODE(endbit, ...)                                                          \
+    do {                                                                                   \
+        if ((endbit) == kEndBit) { constexpr int M = 1; __VA_ARGS__; }                     \
+        else if ((endbit) == kBarrier) { constexpr int M = 2; __VA_ARGS__; }               \
+        else { constexpr int M = 0; __VA_ARGS__; }                                         \
+    } while (0)
+
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint64_t n, uint32_t v) {
     if (!n) return;
     hipLaunchKernelGGL(k_fill_u32, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, s, p, n, v);
@@ -3541,6 +3601,13 @@ void launch_widen(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t 
         hipLaunchKernelGGL(k_widen<true>, dim3(blocks), dim3(256), 0, s, text, n, endmask, tok, n_slots_padded);
     else
         hipLaunchKernelGGL(k_widen<false>, dim3(blocks), dim3(256), 0, s, text, n, endmask, tok, n_slots_padded);
+}
+
+void launch_widen_barrier(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask, uint16_t *tok,
+                          uint64_t n_slots) {
+    if (!n_slots) return;
+    hipLaunchKernelGGL(k_widen_barrier, dim3(blocks_for(n_slots / 16, 256, 8192)), dim3(256), 0, s, text, n, endmask, tok,
+                       n_slots);
 }
 
 void launch_summarize(hipStream_t s, const uint16_t *tok, TileSum *sums, uint32_t n_tiles, int n_cus) {
@@ -3579,8 +3646,7 @@ void launch_first_tiebreak(hipStream_t s, PairTable t, const DevCtl *ctl, unsign
     hipLaunchKernelGGL(k_first_gather, dim3(blocks_for(n_blocks, 4, 2048)), dim3(256), 0, s, t, ctl, best, fs);
     if (n_tiles) {
         const dim3 grid(tile_grid(n_tiles, n_cus, 8)), block(kMergeThreads);
-        if (endbit) hipLaunchKernelGGL(k_first_pos<true>, grid, block, 0, s, tok, sums, n_tiles, t, best, fs);
-        else hipLaunchKernelGGL(k_first_pos<false>, grid, block, 0, s, tok, sums, n_tiles, t, best, fs);
+        MBPE_BY_MODE(endbit, hipLaunchKernelGGL(k_first_pos<M>, grid, block, 0, s, tok, sums, n_tiles, t, best, fs));
     }
     hipLaunchKernelGGL(k_first_pick, dim3(1), dim3(256), 0, s, best, fs);
 }
@@ -3597,35 +3663,30 @@ void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileS
         hipLaunchKernelGGL(k_run_final, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, bs,
                            run_part, left_edge, run_in);
     }
-    static const int occ_c = resident_blocks(k_merge<true, false, 0>), occ_b = resident_blocks(k_merge<false, false, 0>);
-    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b)), block(kMergeThreads);
+    static const int occ[3] = {resident_blocks(k_merge<0, false, 0>), resident_blocks(k_merge<1, false, 0>),
+                               resident_blocks(k_merge<2, false, 0>)};
+    const dim3 grid(tile_grid(n_tiles, n_cus, occ[slot_mode(endbit)])), block(kMergeThreads);
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_MERGE_DIAG") ? atoi(getenv("MBPE_MERGE_DIAG")) : 0;
     if (diag == 1 && !endbit) {
-        hipLaunchKernelGGL((k_merge<false, false, 1>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+        hipLaunchKernelGGL((k_merge<0, false, 1>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq, run_in);
         return;
     }
     if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_merge<false, false, 2>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+        hipLaunchKernelGGL((k_merge<0, false, 2>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq, run_in);
         return;
     }
 #endif
     // (both instantiations: each returns at once unless the pair's frequency is its case)
-    if (endbit) {
-        hipLaunchKernelGGL((k_merge<true, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+    MBPE_BY_MODE(endbit, {
+        hipLaunchKernelGGL((k_merge<M, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
                            m_adj, left_edge, right_edge, seq, run_in);
         if (hot_possible)
-        hipLaunchKernelGGL((k_merge<true, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq, run_in);
-    } else {
-        hipLaunchKernelGGL((k_merge<false, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq, run_in);
-        if (hot_possible)
-        hipLaunchKernelGGL((k_merge<false, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq, run_in);
-    }
+            hipLaunchKernelGGL((k_merge<M, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR,
+                               ctl, m_adj, left_edge, right_edge, seq, run_in);
+    });
 }
 
 void launch_apply(hipStream_t s, PairTable t, DevCtl *ctl, const unsigned long long *best, uint32_t new_id,
@@ -3652,7 +3713,7 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
                          int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap) {
-    const uint32_t fake_id = (endbit ? 0x7FFFu : 0xFFFFu) - 1u;      // see tt_rename
+    const uint32_t fake_id = (endbit == kEndBit ? 0x7FFFu : 0xFFFFu) - 1u;      // see tt_rename
     // stand-in ids of (t,t) members are the kTTMax ids below the hole / end-bit mask: only while no token has them
     const uint32_t tt_max = 256u + n_target <= fake_id + 1u - (uint32_t)kTTMax ? (uint32_t)kTTMax : 1u;
     if (sel_cap < 64u) sel_cap = 64u;
@@ -3674,16 +3735,17 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
                         int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible) {
     if (!n_tiles) return;
-    static const int occ_c = resident_blocks(k_fused_batch<true, false, false, 0>, kLutThreads),
-                     occ_b = resident_blocks(k_fused_batch<false, false, false, 0>, kLutThreads);
-    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kLutThreads);
+    static const int occ[3] = {resident_blocks(k_fused_batch<0, false, false, 0>, kLutThreads),
+                               resident_blocks(k_fused_batch<1, false, false, 0>, kLutThreads),
+                               resident_blocks(k_fused_batch<2, false, false, 0>, kLutThreads)};
+    const dim3 grid(tile_grid(n_tiles, n_cus, occ[slot_mode(endbit)], kLutThreads)), block(kLutThreads);
 #ifdef MBPE_DIAG
     const int diag = getenv("MBPE_FUSED_DIAG") ? atoi(getenv("MBPE_FUSED_DIAG")) : 0;   // (re-read: set after warm-up)
 #define MBPE_FUSED_DIAG_CASE(D)                                                                                            \
     if (diag == D && !endbit) {                                                                                            \
-        hipLaunchKernelGGL((k_fused_batch<false, false, false, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,    \
+        hipLaunchKernelGGL((k_fused_batch<0, false, false, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,        \
                            chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in);                               \
-        hipLaunchKernelGGL((k_fused_batch<false, false, true, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,     \
+        hipLaunchKernelGGL((k_fused_batch<0, false, true, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,         \
                            chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in);                               \
         return;                                                                                                            \
     }
@@ -3693,29 +3755,18 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
     MBPE_FUSED_DIAG_CASE(5)
 #undef MBPE_FUSED_DIAG_CASE
 #endif
-    if (endbit) {
-        hipLaunchKernelGGL((k_fused_batch<true, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+    MBPE_BY_MODE(endbit, {
+        hipLaunchKernelGGL((k_fused_batch<M, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        hipLaunchKernelGGL((k_fused_batch<true, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+        hipLaunchKernelGGL((k_fused_batch<M, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                            LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        if (hot_possible)
-        hipLaunchKernelGGL((k_fused_batch<true, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        if (hot_possible)
-        hipLaunchKernelGGL((k_fused_batch<true, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
-    } else {
-        hipLaunchKernelGGL((k_fused_batch<false, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        hipLaunchKernelGGL((k_fused_batch<false, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        if (hot_possible)
-        hipLaunchKernelGGL((k_fused_batch<false, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
-        if (hot_possible)
-        hipLaunchKernelGGL((k_fused_batch<false, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
-    }
+        if (hot_possible) {
+            hipLaunchKernelGGL((k_fused_batch<M, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in);
+            hipLaunchKernelGGL((k_fused_batch<M, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in);
+        }
+    });
 }
 
 void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1, const TileSum *sums, uint32_t n_tiles,
@@ -3723,55 +3774,36 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
                        const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
                        int n_cus, const uint32_t *run_in, int hot_possible) {
     if (!n_tiles) return;
-    static const int occ_c = resident_blocks(k_scan_batch<true, false, false, 0>, kLutThreads),
-                     occ_b = resident_blocks(k_scan_batch<false, false, false, 0>, kLutThreads);
-    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kLutThreads);
+    static const int occ[3] = {resident_blocks(k_scan_batch<0, false, false, 0>, kLutThreads),
+                               resident_blocks(k_scan_batch<1, false, false, 0>, kLutThreads),
+                               resident_blocks(k_scan_batch<2, false, false, 0>, kLutThreads)};
+    const dim3 grid(tile_grid(n_tiles, n_cus, occ[slot_mode(endbit)], kLutThreads)), block(kLutThreads);
 #ifdef MBPE_DIAG
     static const int diag = getenv("MBPE_SCAN_DIAG") ? atoi(getenv("MBPE_SCAN_DIAG")) : 0;
-    if (diag == 1 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, false, false, 1>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
-                           ctl, left_edge, right_edge, run_in);
-        return;
+#define MBPE_SCAN_DIAG_CASE(D)                                                                                             \
+    if (diag == D && !endbit) {                                                                                            \
+        hipLaunchKernelGGL((k_scan_batch<0, false, false, D>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs,       \
+                           hdr_m, hdr_adj, LR, ctl, left_edge, right_edge, run_in);                                        \
+        return;                                                                                                            \
     }
-    if (diag == 2 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, false, false, 2>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
-                           ctl, left_edge, right_edge, run_in);
-        return;
-    }
-    if (diag == 3 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, false, false, 3>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
-                           ctl, left_edge, right_edge, run_in);
-        return;
-    }
-    if (diag == 4 && !endbit) {
-        hipLaunchKernelGGL((k_scan_batch<false, false, false, 4>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR,
-                           ctl, left_edge, right_edge, run_in);
-        return;
-    }
+    MBPE_SCAN_DIAG_CASE(1)
+    MBPE_SCAN_DIAG_CASE(2)
+    MBPE_SCAN_DIAG_CASE(3)
+    MBPE_SCAN_DIAG_CASE(4)
+#undef MBPE_SCAN_DIAG_CASE
 #endif
-    if (endbit) {
-        hipLaunchKernelGGL((k_scan_batch<true, false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge, run_in);
-        hipLaunchKernelGGL((k_scan_batch<true, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge, run_in);
-        if (hot_possible)
-        hipLaunchKernelGGL((k_scan_batch<true, true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge, run_in);
-        if (hot_possible)
-        hipLaunchKernelGGL((k_scan_batch<true, true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge, run_in);
-    } else {
-        hipLaunchKernelGGL((k_scan_batch<false, false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge, run_in);
-        hipLaunchKernelGGL((k_scan_batch<false, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge, run_in);
-        if (hot_possible)
-        hipLaunchKernelGGL((k_scan_batch<false, true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge, run_in);
-        if (hot_possible)
-        hipLaunchKernelGGL((k_scan_batch<false, true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj, LR, ctl,
-                           left_edge, right_edge, run_in);
-    }
+    MBPE_BY_MODE(endbit, {
+        hipLaunchKernelGGL((k_scan_batch<M, false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj,
+                           LR, ctl, left_edge, right_edge, run_in);
+        hipLaunchKernelGGL((k_scan_batch<M, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj,
+                           LR, ctl, left_edge, right_edge, run_in);
+        if (hot_possible) {
+            hipLaunchKernelGGL((k_scan_batch<M, true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m,
+                               hdr_adj, LR, ctl, left_edge, right_edge, run_in);
+            hipLaunchKernelGGL((k_scan_batch<M, true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m,
+                               hdr_adj, LR, ctl, left_edge, right_edge, run_in);
+        }
+    });
 }
 
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
@@ -3802,20 +3834,16 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok, uint16_t *tok1, const T
     if (!n_tiles) return;
     const uint32_t n_words = (n_tiles + 31u) / 32u;
     hipLaunchKernelGGL(k_list_marked, dim3((n_words + 255) / 256), dim3(256), 0, s, chg, n_words, list, ctl, n_tiles);
-    static const int occ_c = resident_blocks(k_rewrite_marked<true, false>, kLutThreads),
-                     occ_b = resident_blocks(k_rewrite_marked<false, false>, kLutThreads);
-    const dim3 grid(tile_grid(n_tiles, n_cus, endbit ? occ_c : occ_b, kLutThreads)), block(kLutThreads);
-    if (endbit) {
-        hipLaunchKernelGGL((k_rewrite_marked<true, false>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
+    static const int occ[3] = {resident_blocks(k_rewrite_marked<0, false>, kLutThreads),
+                               resident_blocks(k_rewrite_marked<1, false>, kLutThreads),
+                               resident_blocks(k_rewrite_marked<2, false>, kLutThreads)};
+    const dim3 grid(tile_grid(n_tiles, n_cus, occ[slot_mode(endbit)], kLutThreads)), block(kLutThreads);
+    MBPE_BY_MODE(endbit, {
+        hipLaunchKernelGGL((k_rewrite_marked<M, false>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
                            left_edge, right_edge, run_in);
-        hipLaunchKernelGGL((k_rewrite_marked<true, true>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
+        hipLaunchKernelGGL((k_rewrite_marked<M, true>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
                            left_edge, right_edge, run_in);
-    } else {
-        hipLaunchKernelGGL((k_rewrite_marked<false, false>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
-                           left_edge, right_edge, run_in);
-        hipLaunchKernelGGL((k_rewrite_marked<false, true>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
-                           left_edge, right_edge, run_in);
-    }
+    });
 }
 
 void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag, const BatchState *bs) {

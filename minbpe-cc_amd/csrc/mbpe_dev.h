@@ -16,6 +16,10 @@ namespace mbpe {
 // such a token: Tokenizer.h:135-144, :311-319).
 constexpr uint32_t kHole = 0xFFFFu;    // also "no token" in tile summaries
 constexpr uint32_t kEndBit = 0x8000u;  // chunked corpora only
+// A chunked corpus whose ids do not fit 15 bits keeps the chunk ends as BARRIER slots instead: a live token
+// (kBarrier, an id no token has: below the stand-in ids of kTTMax (t,t) members, see MBPE_TT_MAX) after the last
+// token of every chunk.  It belongs to no pair and is never merged; ids then use all 16 bits.
+constexpr uint32_t kBarrier = 0xFFEEu;
 
 constexpr int kTile = 512;             // slots per tile = one wave x 8 slots (one 16-byte load per lane)
 constexpr int kMergeThreads = 256;     // 4 waves per workgroup, each wave walks its own tiles
@@ -152,6 +156,7 @@ struct SelList {
 #define MBPE_TT_MAX 16
 #endif
 constexpr int kTTMax = MBPE_TT_MAX;
+static_assert(0xFFFFu - (uint32_t)MBPE_TT_MAX > kBarrier, "the barrier id must lie below the stand-in ids");
 constexpr uint32_t kTTSlots = 256;
 #ifndef MBPE_SKIP_MAX
 #define MBPE_SKIP_MAX 32
@@ -211,6 +216,9 @@ void launch_pair_count_u8(hipStream_t s, const uint8_t *text, uint64_t n,
 // u8 corpus -> 16-bit slot stream (+END flags), padded to whole tiles with holes
 void launch_widen(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask,
                   uint16_t *tok, uint64_t n_slots_padded);
+// barrier layout: byte i -> slot 2i, slot 2i+1 = barrier or hole; n_slots = 2 * (n rounded up to 256)
+void launch_widen_barrier(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask,
+                          uint16_t *tok, uint64_t n_slots);
 
 // recompute every tile summary from the slots
 void launch_summarize(hipStream_t s, const uint16_t *tok, TileSum *sums, uint32_t n_tiles, int n_cus);

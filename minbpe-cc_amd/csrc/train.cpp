@@ -132,6 +132,8 @@ struct mbpe_ctx {
     uint64_t n_bytes = 0;
     uint64_t n_chunks = 0;
     bool chunked = false;
+    uint64_t n_barriers = 0;     // chunk ends in the corpus (= barrier slots of the barrier layout)
+    bool barrier = false;        // this training keeps the chunk ends as barrier slots (mbpe_dev.h: kBarrier)
     bool loaded = false;
     bool inert = false;          // whole corpus collapses to one token (NUL quirk, basic)
 
@@ -200,6 +202,7 @@ struct mbpe_ctx {
     int64_t opt_threshold_select = 1;   // 0: always select with the bound-walking kernel
     int64_t opt_dense_table = -1;   // -1 auto / 1: dense pair table when vocab <= 32,768; 0: always hashed
     int hot_possible = 1;           // may a batch of the next group of sequences hold a "frequent" pair (kernels' dc_wanted)?
+    int64_t opt_barrier = -1;       // chunk ends as barrier slots: -1 when the ids need 16 bits, 0 never, 1 always
     int64_t opt_first = 0;          // 1: `first` tie-break (insertion order, PairCount.h:65-74) instead of lexical
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
@@ -489,6 +492,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
         if (c->begun) { mbpe_host::set_last_error("conflict_resolution must be set before mbpe_train_begin"); return MBPE_ERR_STATE; }
         c->opt_first = value == 0;
     }
+    else if (n == "chunk_barrier") c->opt_barrier = value < 0 ? -1 : value != 0;       // (read by the next mbpe_train_begin)
     else if (n == "sel_cap") c->opt_sel_cap = std::min<int64_t>(std::max<int64_t>(64, value), kSelCap);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
@@ -503,6 +507,8 @@ int mbpe_load_corpus(mbpe_ctx *c, const uint8_t *text, uint64_t n_bytes, const u
     c->n_bytes = n_bytes;
     c->chunked = chunk_off != nullptr;
     c->n_chunks = chunk_off ? n_chunks : 1;
+    c->n_barriers = 0;
+    c->barrier = false;
     c->inert = false;
     if (chunk_off) {
         if (chunk_off[0] != 0 || chunk_off[n_chunks] != n_bytes) {
@@ -547,6 +553,9 @@ int mbpe_load_corpus(mbpe_ctx *c, const uint8_t *text, uint64_t n_bytes, const u
             }
         }
         c->n_chunks = n_chunks - dropped;
+        uint64_t ends = 0;
+        for (uint8_t b : mask) ends += (uint64_t)__builtin_popcount(b);
+        c->n_barriers = ends;
     } else if (n_bytes && h_text[0] == 0) {
         // one chunk = whole text; stoi only looks at a prefix, 64 bytes are enough
         // to decide unless the prefix is all whitespace (then parse the host copy)
@@ -664,6 +673,9 @@ static inline bool use_hier(const mbpe_ctx *c) {
     return c->h_ctl.n_entries > (1u << 20);
 }
 
+// the chunk-end convention of the stream, as the launchers take it
+static inline uint32_t endbit_of(const mbpe_ctx *c) { return !c->chunked ? 0u : c->barrier ? kBarrier : kEndBit; }
+
 static inline bool is_multi(const mbpe_ctx *c) { return c->n_ranks > 1 || c->opt_force_exchange; }
 
 static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
@@ -675,13 +687,18 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     c->exhausted = false;
 
     const uint64_t n = c->inert ? 0 : c->n_bytes;
-    c->n_slots = std::max<uint64_t>(round_up(n, kTile), kTile);
-    c->cap_slots = c->n_slots;
+    // barrier layout: written sparsely (byte i -> slot 2i, its barrier or a hole behind it) into a first buffer of
+    // twice the size, squeezed into the second one below, and only then does the first one get its final size
+    const uint64_t n_bar = c->barrier ? c->n_barriers : 0;
+    const uint64_t dense_slots = std::max<uint64_t>(round_up(n + n_bar, kTile), kTile);
+    c->n_slots = c->barrier ? std::max<uint64_t>(2 * round_up(n, kTile / 2), kTile) : dense_slots;
+    c->cap_slots = dense_slots;
     if (c->n_slots / kTile > 0x0FFFFFF0ull) { mbpe_host::set_last_error("corpus shard too large"); return MBPE_ERR_ARG; }
     c->n_tiles = (uint32_t)(c->n_slots / kTile);
     c->hdr_words = exchange_header_words(c->n_ranks);
     c->hdrb_words = (batch_header_words() + 3) / 4 * 4;
-    for (int i = 0; i < 2; ++i) HIPCHK(tmalloc(c, &c->tok[i], c->cap_slots * 2));
+    HIPCHK(tmalloc(c, &c->tok[0], c->n_slots * 2));
+    HIPCHK(tmalloc(c, &c->tok[1], c->cap_slots * 2));
     HIPCHK(tmalloc(c, &c->sums, (size_t)c->n_tiles * sizeof(TileSum)));
     HIPCHK(tmalloc(c, &c->side, (size_t)c->n_tiles * sizeof(TileSum)));
     HIPCHK(tmalloc(c, &c->chg, ((size_t)c->n_tiles / 32 + 2) * 4));
@@ -714,7 +731,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(tmalloc(c, &c->best, ((size_t)c->n_target + 2) * 8));
     {
         DevCtl init = {};
-        init.n_live = n;         // every corpus byte starts as one live token
+        init.n_live = n + n_bar;         // every corpus byte starts as one live token
         init.n_ranks = (uint32_t)std::max(1, c->n_ranks);
         c->h_ctl = init;
         HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl, sizeof(DevCtl), hipMemcpyHostToDevice, c->stream));
@@ -736,8 +753,21 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (n >= 2) launch_pair_count_u8(c->stream, c->d_text, n, c->d_endmask, c->xb0, c->n_cus, c->pc_scratch);
     c->cur = 0;
-    launch_widen(c->stream, c->d_text, n, c->d_endmask, c->tok[0], c->n_slots);
-    launch_summarize(c->stream, c->tok[0], c->sums, c->n_tiles, c->n_cus);
+    if (c->barrier) {
+        launch_widen_barrier(c->stream, c->d_text, n, c->d_endmask, c->tok[0], c->n_slots);
+        launch_summarize(c->stream, c->tok[0], c->sums, c->n_tiles, c->n_cus);
+        const double ms_compact = c->stats.ms_compact;
+        rc = do_compact(c);                     // tok[0] -> tok[1]; n_slots / n_tiles are the dense ones from here on
+        if (rc != MBPE_OK) return rc;
+        c->stats.n_compactions--;               // (part of the set-up, not one of the run's compactions)
+        c->stats.ms_compact = ms_compact;
+        tfree(c, c->tok[0]);
+        pool_trim(c);
+        HIPCHK(tmalloc(c, &c->tok[0], c->cap_slots * 2));
+    } else {
+        launch_widen(c->stream, c->d_text, n, c->d_endmask, c->tok[0], c->n_slots);
+        launch_summarize(c->stream, c->tok[0], c->sums, c->n_tiles, c->n_cus);
+    }
     if (is_multi(c)) {
         uint32_t *hdr = c->xb0 + 65536;
         launch_rank_edge(c->stream, c->sums, c->n_tiles, reinterpret_cast<RankEdge *>(hdr + 2) + c->rank, c->ctl, hdr);
@@ -757,7 +787,7 @@ static void update_hot_possible(mbpe_ctx *c, unsigned long long top_count, uint6
 }
 
 static int begin_finish(mbpe_ctx *c) {
-    const uint32_t endbit = c->chunked ? kEndBit : 0;
+    const uint32_t endbit = endbit_of(c);
     if (is_multi(c)) {
         uint32_t *hdr = c->xb0 + 65536;
         launch_boundary_pairs(c->stream, c->xb0, hdr, c->n_ranks, endbit);
@@ -783,7 +813,7 @@ static int begin_finish(mbpe_ctx *c) {
 }
 
 static void step_local(mbpe_ctx *c, int ev_slot) {
-    const uint32_t endbit = c->chunked ? kEndBit : 0;
+    const uint32_t endbit = endbit_of(c);
     const uint32_t X = 256 + c->k;
     const bool multi = is_multi(c);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
@@ -807,7 +837,7 @@ static void step_finish(mbpe_ctx *c) {
     launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1, use_hier(c));
     if (c->opt_first)
         launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best + c->k + 1, c->first_state, c->tok[c->cur], c->sums,
-                              c->n_tiles, c->chunked ? kEndBit : 0, c->n_cus);
+                              c->n_tiles, endbit_of(c), c->n_cus);
     c->k++;
 }
 
@@ -825,7 +855,7 @@ static size_t step_exchange_words(const mbpe_ctx *c) { return exchange_words(c, 
 static inline bool use_batches(const mbpe_ctx *c) { return c->opt_multi_merge != 0 && !c->opt_first; }
 
 static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exchange
-    const uint32_t endbit = c->chunked ? kEndBit : 0;
+    const uint32_t endbit = endbit_of(c);
     const bool multi = is_multi(c);
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
     launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best,
@@ -847,7 +877,7 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
 }
 
 static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge exchange
-    const uint32_t endbit = c->chunked ? kEndBit : 0;
+    const uint32_t endbit = endbit_of(c);
     const bool multi = is_multi(c);
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
     c->k_upper = std::min<uint32_t>(c->n_target, c->k_upper + (uint32_t)c->opt_max_batch);
@@ -905,12 +935,13 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     if (!c) return MBPE_ERR_ARG;
     if (!c->loaded) { mbpe_host::set_last_error("mbpe_train_begin: no corpus loaded"); return MBPE_ERR_STATE; }
     if (vocab_size < 256) { mbpe_host::set_last_error("vocab_size must be >= 256"); return MBPE_ERR_ARG; }
-    const uint32_t vmax = c->chunked ? MBPE_MAX_VOCAB_CHUNKED : MBPE_MAX_VOCAB_BASIC;
+    const uint32_t vmax = !c->chunked ? MBPE_MAX_VOCAB_BASIC : c->opt_barrier == 0 ? MBPE_MAX_VOCAB_ENDBIT : MBPE_MAX_VOCAB_CHUNKED;
+    c->barrier = c->chunked && (c->opt_barrier == 1 || (c->opt_barrier != 0 && vocab_size > MBPE_MAX_VOCAB_ENDBIT));
     if (vocab_size > vmax) {
         mbpe_host::set_last_error("vocab_size exceeds the 16-bit slot format (" + std::to_string(vmax) + ")");
         return MBPE_ERR_VOCAB;
     }
-    if (c->opt_first && (is_multi(c) || c->n_bytes >= 0xFFFFFE00ull)) {
+    if (c->opt_first && (is_multi(c) || c->n_bytes + (c->barrier ? c->n_barriers : 0) >= 0xFFFFFE00ull)) {
         mbpe_host::set_last_error("conflict_resolution first: one GPU and a corpus below 4 GiB only");
         return MBPE_ERR_STATE;
     }
@@ -1208,7 +1239,7 @@ int mbpe_train_result(mbpe_ctx *c, uint32_t *merges_out, int32_t *counts_out, ui
 int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
     if (!c || !out) return MBPE_ERR_ARG;
     c->stats.n_slots = c->begun ? c->n_slots : 0;
-    c->stats.n_live = c->begun ? c->h_ctl.n_live : 0;
+    c->stats.n_live = c->begun ? c->h_ctl.n_live - (c->barrier ? c->n_barriers : 0) : 0;      // (barriers are no tokens)
     c->stats.n_merges = c->exhausted ? 0 : c->n_valid;
     c->stats.n_pairs = c->begun ? c->h_ctl.n_entries : 0;
     c->stats.n_batches = c->begun ? (use_batches(c) ? c->h_ctl.n_batches : c->k) : 0;
@@ -1264,14 +1295,19 @@ int mbpe_get_stream(mbpe_ctx *c, uint32_t *tokens_out, uint8_t *chunk_end_out, u
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<uint16_t> h(c->n_slots);
     HIPCHK(hipMemcpy(h.data(), c->tok[c->cur], c->n_slots * 2, hipMemcpyDeviceToHost));
-    const uint32_t idmask = c->chunked ? 0x7FFFu : 0xFFFFu;
+    const bool endflag = c->chunked && !c->barrier;
+    const uint32_t idmask = endflag ? 0x7FFFu : 0xFFFFu;
     uint64_t w = 0;
     for (uint64_t i = 0; i < c->n_slots; ++i) {
         if (h[i] == kHole) continue;
+        if (c->barrier && h[i] == kBarrier) {          // ends the chunk of the token before it
+            if (tokens_out && chunk_end_out && w) chunk_end_out[w - 1] = 1;
+            continue;
+        }
         if (tokens_out) {
             if (w >= cap) { mbpe_host::set_last_error("tokens_out too small"); return MBPE_ERR_ARG; }
             tokens_out[w] = h[i] & idmask;
-            if (chunk_end_out) chunk_end_out[w] = c->chunked ? (h[i] >> 15) & 1 : 0;
+            if (chunk_end_out) chunk_end_out[w] = endflag ? (h[i] >> 15) & 1 : 0;
         }
         ++w;
     }
@@ -1280,7 +1316,7 @@ int mbpe_get_stream(mbpe_ctx *c, uint32_t *tokens_out, uint8_t *chunk_end_out, u
 }
 
 int mbpe_stream_device(mbpe_ctx *c, const void **slots_out, uint64_t *n_slots_out, uint32_t *slot_bits_out,
-                       uint32_t *end_bit_out) {
+                       uint32_t *end_bit_out, uint32_t *barrier_out) {
     if (!c || !slots_out || !n_slots_out) return MBPE_ERR_ARG;
     if (!c->begun) { mbpe_host::set_last_error("mbpe_stream_device before mbpe_train_begin"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
@@ -1289,7 +1325,8 @@ int mbpe_stream_device(mbpe_ctx *c, const void **slots_out, uint64_t *n_slots_ou
     *slots_out = c->tok[c->cur];
     *n_slots_out = c->n_slots;
     if (slot_bits_out) *slot_bits_out = 16;
-    if (end_bit_out) *end_bit_out = c->chunked ? kEndBit : 0;
+    if (end_bit_out) *end_bit_out = c->chunked && !c->barrier ? kEndBit : 0;
+    if (barrier_out) *barrier_out = c->barrier ? kBarrier : MBPE_NO_BARRIER;
     return MBPE_OK;
 }
 

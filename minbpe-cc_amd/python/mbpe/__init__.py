@@ -91,7 +91,8 @@ def lib():
     L.mbpe_train.argtypes = [vp, vp, u64, vp, u64, u32, i32, vp, vp, vp, vp]
     L.mbpe_get_stats.argtypes = [vp, vp]
     L.mbpe_get_stream.argtypes = [vp, vp, vp, u64, vp]
-    L.mbpe_stream_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.mbpe_stream_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(u32), ctypes.POINTER(u32),
+                                     ctypes.POINTER(u32)]
     L.mbpe_table_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u32)]
     L.mbpe_get_pairs.argtypes = [vp, vp, vp, vp, u64, vp]
     L.mbpe_compact.argtypes = [vp]
@@ -332,11 +333,13 @@ class Trainer:
         return toks[:n.value], ends[:n.value]
 
     def stream_device(self):
-        """(device pointer, n_slots, slot_bits, end_bit) of the live slot stream (see mbpe_stream_device)."""
+        """(device pointer, n_slots, slot_bits, end_bit, barrier or None) of the live slot stream (see
+        mbpe_stream_device)."""
         p, n = ctypes.c_void_p(), ctypes.c_uint64()
-        bits, end = ctypes.c_uint32(), ctypes.c_uint32()
-        _check(lib().mbpe_stream_device(self._h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(bits), ctypes.byref(end)))
-        return p.value, n.value, bits.value, end.value
+        bits, end, bar = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        _check(lib().mbpe_stream_device(self._h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(bits), ctypes.byref(end),
+                                        ctypes.byref(bar)))
+        return p.value, n.value, bits.value, end.value, (None if bar.value == 0xFFFFFFFF else bar.value)
 
     def table_device(self):
         """(device pointer, vshift) of the dense pair table (see mbpe_table_device)."""

@@ -27,8 +27,10 @@ def token_tables(merges, max_len=None):
 
 
 def live_tokens(tr, torch, device, lo=0, hi=None):
-    """Token ids (int32) and chunk-end flags (bool) of the live slots in [lo, hi) of the device stream."""
-    ptr, n_slots, bits, end_bit = tr.stream_device()
+    """Token ids (int32) and chunk-end flags (bool) of the live slots in [lo, hi) of the device stream.
+    (Barrier layout: a token is the last of its chunk when a barrier slot follows it; a barrier that is the
+    first live slot of the range belongs to a token before the range.)"""
+    ptr, n_slots, bits, end_bit, barrier = tr.stream_device()
     hi = n_slots if hi is None else min(hi, n_slots)
     if bits == 16:
         raw = _as_tensor(torch, ptr + 2 * lo, hi - lo, torch.int16, device).to(torch.int32) & 0xFFFF
@@ -37,6 +39,12 @@ def live_tokens(tr, torch, device, lo=0, hi=None):
         raw = _as_tensor(torch, ptr + 4 * lo, hi - lo, torch.int32, device)
         hole = -1
     raw = raw[raw != hole]
+    if barrier is not None:
+        is_bar = raw == barrier
+        ends = torch.zeros_like(is_bar)
+        ends[:-1] = is_bar[1:]
+        keep = ~is_bar
+        return raw[keep], ends[keep]
     if end_bit:
         return raw & ~end_bit, (raw & end_bit) != 0
     return raw, None
@@ -62,7 +70,7 @@ def decode_roundtrip(tr, merges, corpus, torch, device, slots_per_piece=1 << 28)
     lens_t = torch.from_numpy(lens_h).to(device)
     tab_t = torch.from_numpy(tab_h).to(device)
     width = tab_h.shape[1]
-    _, n_slots, _, _ = tr.stream_device()
+    n_slots = tr.stream_device()[1]
     base = 0
     n_live = 0
     ok = True
@@ -107,7 +115,7 @@ def decoded_length(tr, merges, torch, device, slots_per_piece=1 << 28):
     cover exactly the byte range it was loaded with)."""
     lens_h, _ = token_tables(merges)
     lens_t = torch.from_numpy(lens_h).to(device)
-    _, n_slots, _, _ = tr.stream_device()
+    n_slots = tr.stream_device()[1]
     total = 0
     for lo in range(0, n_slots, slots_per_piece):
         toks, _ = live_tokens(tr, torch, device, lo, lo + slots_per_piece)

@@ -92,3 +92,18 @@ def test_tokenizer_train_binding():
     assert O.model_bytes(O.GPT2_SPLIT_PATTERN, tok.merges()) == read_golden("taylorswift_gpt2_lexical_512.model")
     data = read_data("sample.txt")
     assert tok.decode(tok.encode(data)) == data
+
+
+def test_e2e_gpt4_vocab_40000(tmp_path):
+    # a GPT-style vocabulary with the split pattern: ids beyond 15 bits (the stream keeps chunk ends as barrier
+    # slots, see tests/test_gpu_barrier.py); model bytes against the oracle, then the reference's round trip
+    model, enc, dec = tmp_path / "big-model", tmp_path / "enc", tmp_path / "dec"
+    src = os.path.join(DATA, "taylorswift.txt")
+    out = _run("-t", "-i", src, "-m", model, "-c", "lexical", "--vocab-size", 40000)
+    assert "Writing model..." in out
+    data = read_data("taylorswift.txt")
+    want_m, _ = O.train(data, 40000, mbpe.presplit(O.GPT4_SPLIT_PATTERN, data))
+    assert model.read_bytes() == O.model_bytes(O.GPT4_SPLIT_PATTERN, want_m)
+    _run("-e", "-i", src, "-m", model, "-o", enc)
+    _run("-d", "-i", enc, "-m", model, "-o", dec)
+    assert dec.read_bytes() == data

@@ -26,6 +26,7 @@ def hip():
 
 
 FUSED_MIN = 24
+EXTRA_OPTS = {}       # further options set on every rank's context
 
 
 @pytest.fixture(params=[2, 1000], autouse=True, ids=["fused", "scan_rewrite"])
@@ -60,6 +61,8 @@ def _train_sharded(data, cuts, vocab, chunk_off=None, decode_check=False):
             lo, hi = bounds[r], bounds[r + 1]
             t.comm_init_external(r, R)
             t.set_option("fused_min", FUSED_MIN)
+            for k, v in EXTRA_OPTS.items():
+                t.set_option(k, v)
             off = None
             if chunk_off is not None:
                 sel = chunk_off[(chunk_off >= lo) & (chunk_off <= hi)]
@@ -166,6 +169,23 @@ def test_chunked_shards_text():
     off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data)
     cuts = [int(off[len(off) // 3]), int(off[2 * len(off) // 3])]
     _check(data, cuts, 256 + 40, off)
+
+
+def test_chunked_shards_barrier_layout():
+    # chunk ends as barrier slots (the layout of vocabularies beyond 32,766 ids): a shard then ends on a barrier,
+    # which its right neighbour sees as the token before its first one
+    global EXTRA_OPTS
+    EXTRA_OPTS = {"chunk_barrier": 1}
+    try:
+        data = read_data("taylorswift.txt")[:50000]
+        off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data)
+        _check(data, [int(off[len(off) // 3]), int(off[2 * len(off) // 3])], 256 + 40, off)
+        rng = np.random.default_rng(31)
+        data = rng.integers(97, 100, size=6000, dtype=np.uint8).tobytes()
+        off = np.array(sorted(set([0, 6000] + [int(x) for x in rng.integers(1, 6000, size=900)])), dtype=np.uint64)
+        _check(data, [int(off[100]), int(off[101]), int(off[500])], 256 + 30, off)      # (one shard of a single chunk)
+    finally:
+        EXTRA_OPTS = {}
 
 
 def test_text_three_ranks():
