@@ -1036,6 +1036,16 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
             unsigned long long last = 0;
             HIPCHK(hipMemcpy(&last, c->best + (c->k - 1), 8, hipMemcpyDeviceToHost));
             update_hot_possible(c, last >> 32, (uint64_t)seqs_per_sync(c) * kBatchMax);
+            if ((last >> 32) == 0 && c->k < target && c->k != before) {
+                // The best pair no longer occurs anywhere.  Merging it changes neither the stream nor the table, so the
+                // reference chooses it again and again (its loop only ends on an empty table, Tokenizer.h:586-588;
+                // PairCountLexicalOrder never erases): every remaining merge of this call is that pair.
+                std::vector<unsigned long long> rest(target - c->k, last);
+                HIPCHK(hipMemcpy(c->best + c->k, rest.data(), rest.size() * 8, hipMemcpyHostToDevice));
+                HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->ctl->k_done), (int)target, 1, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                c->k = c->h_ctl.k_done = target;
+            }
         }
         rc = after_batch(c);
         if (rc != MBPE_OK) return rc;
