@@ -191,7 +191,6 @@ struct mbpe_ctx {
     // options
     int64_t opt_compact_den = 16;
     int64_t opt_batch = 64;
-    int64_t opt_use_graph = 1;
     int64_t opt_time_kernels = 0;   // HIP events around every merge kernel (bench.py)
     int64_t opt_force_exchange = 0; // run the multi-rank path (edges, exchange) even with one rank
     int64_t opt_hier_argmax = -1;   // -1 auto (by table size), 0 full scan, 1 hierarchical
@@ -478,7 +477,6 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     std::string n(name);
     if (n == "compact_den") c->opt_compact_den = value;
     else if (n == "batch") c->opt_batch = std::max<int64_t>(1, value);
-    else if (n == "use_graph") c->opt_use_graph = value;
     else if (n == "time_kernels") c->opt_time_kernels = value;
     else if (n == "force_exchange") c->opt_force_exchange = value;
     else if (n == "hier_argmax") c->opt_hier_argmax = value;
