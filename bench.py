@@ -8,7 +8,7 @@ A "step" is one *batch sequence*, the unit the library executes (mbpe_train_sequ
 select the next maxima that are provably independent -> ONE pass over the token stream that
 merges them all -> validate against the reference's one-at-a-time order -> apply the count
 updates.  It is the loop body of the reference (Tokenizer.h:557-589: get_top_pair_count,
-merge_chunks -> merge_incremental) for up to 512 consecutive iterations at once.  W warm-up
+merge_chunks -> merge_incremental) for up to 1024 consecutive iterations at once.  W warm-up
 sequences run untimed, then exactly K sequences are timed between barriers;
     value = merges those K sequences committed / wall time       (merges/s, whole job)
 
@@ -129,7 +129,10 @@ def cpu_baseline(data, merges, what):
     }
 
 
-FUSED_LIMITER = ("vector instruction issue, not HBM (SQ counters in profiles/, DESIGN.md section 4)")
+FUSED_LIMITER = ("per-match work on top of the pass's copy floor (3.4 ms for 17.2 GB = 0.64 of peak): two scattered global "
+                 "atomics per match (the atomic unit does 24 G/s whatever the table size, tools/atomic_footprint.hip) and "
+                 "vector-instruction issue; a pass of up to 1024 merges holds ~3.5e7 matches (DESIGN.md section 4, "
+                 "profiles/r02_fused_ablation.md)")
 
 
 def main():

@@ -1624,7 +1624,7 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 #endif
 constexpr uint32_t kBucketKeys = MBPE_LUT_KEYS;          // keys per bucket: 2 (8-byte read) or 4 (16-byte read)
 #ifndef MBPE_LUT_BUCKETS
-#define MBPE_LUT_BUCKETS (8192 / MBPE_LUT_KEYS)      /* 4096 buckets of two keys: 32 KB + 16 KB of indices */
+#define MBPE_LUT_BUCKETS (16384 / MBPE_LUT_KEYS)     /* 8192 buckets of two keys: 64 KB + 32 KB of indices */
 #endif
 constexpr uint32_t kBuckets = MBPE_LUT_BUCKETS;
 static_assert((kBuckets & (kBuckets - 1u)) == 0, "the hash is masked");
@@ -2008,6 +2008,13 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                                                            uint32_t tt_max) {
     __shared__ unsigned long long sp[kSelCap];
     __shared__ uint32_t si[kSelCap];
+    // what the members accepted so far occupy (the independence test of a candidate is then a few LDS reads,
+    // whatever the batch size): is a token the FIRST / SECOND element of a member (exact bitmaps), how many
+    // members have it there (8-bit counts, ids folded to 15 bits: only the pass-over prediction uses them),
+    // and how many keys every bucket of the kernels' lookup table holds
+    __shared__ uint32_t set_first[2048], set_second[2048];
+    __shared__ uint8_t cnt_first[32768], cnt_second[32768];
+    __shared__ uint8_t bucket_fill[kBuckets];
     const uint32_t tid = threadIdx.x;
     if (attempt > 0 && (ctl->sel_ok || !ctl->sel_retry)) return;
     const uint32_t k0 = ctl->k_done;
@@ -2039,6 +2046,12 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         sp[i] = i < n_l ? sel->packed[i] : 0ull;
         si[i] = i < n_l ? sel->eidx[i] : 0u;
     }
+    for (uint32_t i = tid; i < 2048u; i += kPickThreads) { set_first[i] = 0; set_second[i] = 0; }
+    for (uint32_t i = tid; i < 32768u / 4u; i += kPickThreads) {
+        reinterpret_cast<uint32_t *>(cnt_first)[i] = 0;
+        reinterpret_cast<uint32_t *>(cnt_second)[i] = 0;
+    }
+    for (uint32_t i = tid; i < kBuckets / 4u; i += kPickThreads) reinterpret_cast<uint32_t *>(bucket_fill)[i] = 0;
     __syncthreads();
     // bitonic sort, descending by packed value (unique per pair: a total order)
     for (uint32_t k = 2; k <= n_sort; k <<= 1) {
@@ -2086,13 +2099,9 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
     if (limit > max_batch) limit = max_batch;
     if (limit > (uint32_t)kBatchMax) limit = kBatchMax;
     if (limit > adapt) limit = adapt;
-    // the independent prefix (one wave; lane i remembers accepted pairs i, i + 64, ...)
-    if (tid < (uint32_t)kWave) {
-        constexpr int kPer = (kBatchMax + kWave - 1) / kWave;
+    // the independent prefix (sequential by nature: one thread; everything it looks at is in LDS)
+    if (tid == 0) {
         uint32_t accepted = 0;
-        uint32_t my_a[kPer], my_b[kPer], my_h[kPer];
-#pragma unroll
-        for (int r = 0; r < kPer; ++r) my_a[r] = my_b[r] = my_h[r] = 0xFFFFFFFFu;
         uint32_t cut = 0;      // 1 conflict, 2 bucket, 3 single
         uint32_t n_skip = 0, ci = 0;
         // (on text a dependent pair often does NOT fall behind -- few of its occurrences overlap the
@@ -2115,52 +2124,43 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             const bool single = count == 0 || (tt && (n_tt >= tt_max || ((tt_slots[slot >> 6] >> (slot & 63u)) & 1ull)));
             const uint32_t h = pair_hash(a, tt ? fake_id - n_tt : b);
             if (accepted > 0) {
-                bool c1 = false;
-                uint32_t same_l = 0, conf_l = 0;
-#pragma unroll
-                for (int r = 0; r < kPer; ++r) {      // (unused slots hold 0xFFFFFFFF: never equal)
-                    const uint32_t k1 = (b == my_a[r] ? 1u : 0u) + (a == my_b[r] ? 1u : 0u);
-                    conf_l += k1;
-                    c1 |= k1 != 0u;
-                    same_l += my_h[r] == h ? 1u : 0u;
-                }
-                const unsigned long long conf = __ballot(c1);
-                const uint32_t same = wave_sum(same_l);
+                // dependent on an earlier member (c, d): b == c or a == d
+                const bool conf = (((set_first[b >> 5] >> (b & 31u)) | (set_second[a >> 5] >> (a & 31u))) & 1u) != 0u;
+                const uint32_t same = bucket_fill[h];
                 if (single) { cut = 3u; break; }
-                if (conf != 0ull && n_skip < (uint32_t)kSkipMax && skip_allowed) {
+                if (conf && n_skip < (uint32_t)kSkipMax && skip_allowed) {
                     // Depends on an earlier member (shares a token with it the wrong way round): the
                     // earlier merge eats some of its occurrences, so its count will have dropped by the
                     // time it could be chosen -- normally below the whole batch.  Pass it over;
                     // k_validate checks from the measured deltas that it really fell behind every
                     // member chosen after this point, and cuts the batch here otherwise.
-                    if (tid == 0) {
-                        bs->skip_key[n_skip] = key;
-                        bs->skip_pos[n_skip] = accepted;
-                        bs->skip_packed[n_skip] = cand;
-                    }
+                    bs->skip_key[n_skip] = key;
+                    bs->skip_pos[n_skip] = accepted;
+                    bs->skip_packed[n_skip] = cand;
                     ++n_skip;
                     // (it loses occurrences to every member it depends on: red_q16 is the fraction per such member)
-                    unsigned long long lose = (unsigned long long)wave_sum(conf_l) * red_q16;
+                    const uint32_t n_dep = (uint32_t)cnt_first[b & 0x7FFFu] + cnt_second[a & 0x7FFFu];
+                    unsigned long long lose = (unsigned long long)n_dep * red_q16;
                     if (lose > 65536ull) lose = 65536ull;
                     const unsigned long long keep = (unsigned long long)count - (((unsigned long long)count * lose) >> 16);
                     const unsigned long long fl = (keep << 32) | (uint32_t)cand;
                     skip_floor = fl > skip_floor ? fl : skip_floor;
                     continue;
                 }
-                if (conf != 0ull || same >= kBucketKeys) { cut = conf ? 1u : 2u; break; }
+                if (conf || same >= kBucketKeys) { cut = conf ? 1u : 2u; break; }
                 if (cand < skip_floor) { cut = 1u; break; }
             }
-#pragma unroll
-            for (int r = 0; r < kPer; ++r)
-                if (accepted == (uint32_t)r * kWave + tid) { my_a[r] = a; my_b[r] = b; my_h[r] = h; }
-            if (tid == 0) {
-                bs->key[accepted] = key;
-                bs->eidx[accepted] = si[ci];
-                bs->packed[accepted] = cand;
-                bs->maxp[accepted] = 0;
-                best[k0 + accepted] = cand;
-                if (tt && n_tt == 0) { bs->tt_index = accepted; bs->tt_token = a; }
-            }
+            set_first[a >> 5] |= 1u << (a & 31u);
+            set_second[b >> 5] |= 1u << (b & 31u);
+            if (cnt_first[a & 0x7FFFu] != 0xFFu) cnt_first[a & 0x7FFFu] += 1;
+            if (cnt_second[b & 0x7FFFu] != 0xFFu) cnt_second[b & 0x7FFFu] += 1;
+            bucket_fill[h] += 1;
+            bs->key[accepted] = key;
+            bs->eidx[accepted] = si[ci];
+            bs->packed[accepted] = cand;
+            bs->maxp[accepted] = 0;
+            best[k0 + accepted] = cand;
+            if (tt && n_tt == 0) { bs->tt_index = accepted; bs->tt_token = a; }
             if (tt) { tt_slots[slot >> 6] |= 1ull << (slot & 63u); ++n_tt; }
             ++accepted;
             if (single) { cut = 3u; ++ci; break; }

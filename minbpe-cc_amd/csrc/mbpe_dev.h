@@ -26,7 +26,7 @@ constexpr int kMergeThreads = 256;     // 4 waves per workgroup, each wave walks
 // the kernels that hold the batch lookup table in LDS: one table per workgroup, so a large table
 // wants a large workgroup (4 waves per SIMD either way)
 #ifndef MBPE_LUT_THREADS
-#define MBPE_LUT_THREADS 512
+#define MBPE_LUT_THREADS 1024
 #endif
 constexpr int kLutThreads = MBPE_LUT_THREADS;
 constexpr int kSlotsPerLane = 8;
@@ -135,7 +135,7 @@ struct DevCtl {
 // A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
 // stream (see k_select_batch).  Per batch scratch, device memory:
 #ifndef MBPE_BATCH_MAX
-#define MBPE_BATCH_MAX 512
+#define MBPE_BATCH_MAX 1024
 #endif
 constexpr int kBatchMax = MBPE_BATCH_MAX;
 static_assert((kBatchMax & (kBatchMax - 1)) == 0 && kBatchMax >= 64,
