@@ -2180,7 +2180,10 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             if (cut == 0u && accepted == limit) ctl->cut_full += 1;
             // next threshold: about 128 candidates beyond this batch, or a window twice as wide
             // when the list ended before the batch was full
-            const uint32_t want = ci + 2u * (adapt < 16u ? 16u : adapt);
+#ifndef MBPE_SEL_AHEAD
+#define MBPE_SEL_AHEAD 2        /* halves of the batch-size limit that the next candidate list should reach beyond a batch */
+#endif
+            const uint32_t want = ci + ((uint32_t)MBPE_SEL_AHEAD * (adapt < 16u ? 16u : adapt)) / 2u;
             if (n_l > want) {
                 ctl->sel_T = sp[want];          // (the full packed value: also cuts inside a run of equal counts)
             } else {
@@ -2861,7 +2864,8 @@ __global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, con
             mp = p > mp ? p : mp;
         }
     }
-    if (mp) atomicMax(&bs->maxp[j], mp);
+    // (maxp only grows: most threads see that another one already put a larger value there)
+    if (mp > __hip_atomic_load(&bs->maxp[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bs->maxp[j], mp);
 }
 
 // How many pairs of the batch the sequential algorithm would really have chosen in this order
@@ -2874,16 +2878,19 @@ __global__ __launch_bounds__(256) void k_adj_max(const uint32_t *__restrict__ hd
     const uint32_t n = ctl->batch_n;
     if (n < 2) return;
     const uint32_t X0 = 256u + ctl->k_done;
-    const uint32_t i2 = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t p = i2 / kBatchMax, q = i2 % kBatchMax;
-    if (p >= n || q >= n) return;
-    const uint32_t w = hdr_adj[i2];
-    if (!w) return;
-    const uint32_t bp = bs->key[p] & 0xFFFFu, aq = bs->key[q] >> 16;
-    const unsigned long long xx = pack_best((int32_t)w, ((X0 + p) << 16) | (X0 + q));            // (X_p, X_q)
-    atomicMax(&bs->maxp[q > p ? q : p], xx);
-    atomicMax(&bs->maxp[q], pack_best((int32_t)bs->adj_in[q], (bp << 16) | (X0 + q)));          // (b_p, X_q), p not merged
-    atomicMax(&bs->maxp[p], pack_best((int32_t)bs->adj_out[p], ((X0 + p) << 16) | aq));         // (X_p, a_q), q not merged
+    // rows p of the n x n block, a wave per row at a time, lanes along q (the cells of a row are contiguous)
+    const uint32_t n_waves = gridDim.x * (blockDim.x / kWave);
+    for (uint32_t p = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; p < n; p += n_waves) {
+        for (uint32_t q = lane_id(); q < n; q += kWave) {
+            const uint32_t w = hdr_adj[p * kBatchMax + q];
+            if (!w) continue;
+            const uint32_t bp = bs->key[p] & 0xFFFFu, aq = bs->key[q] >> 16;
+            const unsigned long long xx = pack_best((int32_t)w, ((X0 + p) << 16) | (X0 + q));            // (X_p, X_q)
+            atomicMax(&bs->maxp[q > p ? q : p], xx);
+            atomicMax(&bs->maxp[q], pack_best((int32_t)bs->adj_in[q], (bp << 16) | (X0 + q)));          // (b_p, X_q), p not merged
+            atomicMax(&bs->maxp[p], pack_best((int32_t)bs->adj_out[p], ((X0 + p) << 16) | aq));         // (X_p, a_q), q not merged
+        }
+    }
 }
 
 __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m,
@@ -3814,8 +3821,9 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     if (blocks > 2048) blocks = 2048;
     if (blocks < 2) blocks = 2;
     hipLaunchKernelGGL(k_adj_sums, dim3(kBatchMax), dim3(kWave), 0, s, hdr_adj, bs, ctl);
-    hipLaunchKernelGGL(k_delta_max, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, LR, bs, ctl);
-    hipLaunchKernelGGL(k_adj_max, dim3(kBatchMax * kBatchMax / 256), dim3(256), 0, s, hdr_adj, bs, ctl);
+    // (the grid's thread count stays a multiple of kBatchMax: see the kernel)
+    hipLaunchKernelGGL(k_delta_max, dim3(blocks < 1024 ? (blocks + 3u) / 4u * 4u : 1024), dim3(256), 0, s, LR, bs, ctl);
+    hipLaunchKernelGGL(k_adj_max, dim3(kBatchMax / 4), dim3(256), 0, s, hdr_adj, bs, ctl);
     hipLaunchKernelGGL(k_validate, dim3(1), dim3(kValThreads), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     if (t.cells) {
         uint32_t grid = ((id_upper + kApplyTile - 1) / kApplyTile) * (kBatchMax / kApplyTile);
