@@ -2885,10 +2885,13 @@ __global__ __launch_bounds__(256) void k_adj_max(const uint32_t *__restrict__ hd
             const uint32_t w = hdr_adj[p * kBatchMax + q];
             if (!w) continue;
             const uint32_t bp = bs->key[p] & 0xFFFFu, aq = bs->key[q] >> 16;
-            const unsigned long long xx = pack_best((int32_t)w, ((X0 + p) << 16) | (X0 + q));            // (X_p, X_q)
-            atomicMax(&bs->maxp[q > p ? q : p], xx);
-            atomicMax(&bs->maxp[q], pack_best((int32_t)bs->adj_in[q], (bp << 16) | (X0 + q)));          // (b_p, X_q), p not merged
-            atomicMax(&bs->maxp[p], pack_best((int32_t)bs->adj_out[p], ((X0 + p) << 16) | aq));         // (X_p, a_q), q not merged
+            // (maxp only grows: an atomic only where the value would still raise it)
+            auto raise = [&](uint32_t j, unsigned long long v) {
+                if (v > __hip_atomic_load(&bs->maxp[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bs->maxp[j], v);
+            };
+            raise(q > p ? q : p, pack_best((int32_t)w, ((X0 + p) << 16) | (X0 + q)));                      // (X_p, X_q)
+            raise(q, pack_best((int32_t)bs->adj_in[q], (bp << 16) | (X0 + q)));          // (b_p, X_q), p not merged
+            raise(p, pack_best((int32_t)bs->adj_out[p], ((X0 + p) << 16) | aq));         // (X_p, a_q), q not merged
         }
     }
 }
