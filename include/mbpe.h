@@ -237,7 +237,7 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *   "compact_den"   compact when holes * den >= slots (default 16; 0 = never)
  *   "batch"         sequences (or single merges) per host round trip (default 64)
  *   "multi_merge"   1 = several independent merges per stream pass (default), 0 = one
- *   "max_batch"     most merges one pass may take (default and limit 512)
+ *   "max_batch"     most merges one pass may take (default and limit 1024)
  *   "fused_min"     batches of at least this many pairs read the stream once and write
  *                   the merged stream to the second buffer (default 24; frequent pairs
  *                   qualify earlier); 2 = every multi-pair batch, >= 1000 = never
