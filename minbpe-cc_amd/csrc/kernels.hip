@@ -1632,7 +1632,7 @@ constexpr uint32_t kEmptyPair = 0xFFFEFFFEu;
 static_assert(kBucketKeys == 2 || kBucketKeys == 4, "bucket = one 8- or 16-byte LDS read");
 
 static_assert(kBatchMax <= 65536, "batch indices are stored in 16 bits");
-struct BatchLut {
+struct BatchLutMem {             // (in LDS, one per workgroup)
 #if MBPE_LUT_KEYS == 2
     uint2 bucket[kBuckets];
     uint32_t bidx[kBuckets];     // batch index of bucket.x (low half) and bucket.y (high half)
@@ -1641,9 +1641,23 @@ struct BatchLut {
     uint2 bidx[kBuckets];        // batch indices of bucket.x .. bucket.w, 16 bits each
 #endif
 };
+// The hash of a batch's table is second * mul + first (one v_mad_u32_u24), masked; mul is chosen per batch by the
+// selection among kHashMul so that no bucket needs a third key for as long as possible (BatchState::hash_mul) and
+// reaches the stream kernels in a scalar register.
+#ifndef MBPE_HASH_SEEDS
+#define MBPE_HASH_SEEDS 8
+#endif
+constexpr int kHashSeeds = MBPE_HASH_SEEDS;
+__device__ __constant__ const uint32_t kHashMul[8] = {2531u, 40503u, 10007u, 60493u, 25013u, 7919u, 52361u, 33391u};
+static_assert(kHashSeeds >= 1 && kHashSeeds <= 8, "kHashMul");
+struct BatchLut {
+    BatchLutMem *m;
+    uint32_t mul;                // uniform
+    __device__ __forceinline__ BatchLut(BatchLutMem *mem, const BatchState *bs) : m(mem), mul(rfl(bs->hash_mul)) {}
+};
 
-__device__ __forceinline__ uint32_t pair_hash(uint32_t first, uint32_t second) {
-    return (__umul24(second, 2531u) + first) & (kBuckets - 1u);      // one v_mad_u32_u24
+__device__ __forceinline__ uint32_t pair_hash(uint32_t mul, uint32_t first, uint32_t second) {
+    return (__umul24(second, mul) + first) & (kBuckets - 1u);      // one v_mad_u32_u24
 }
 
 // The (t,t) members of the batch, for the kernel instantiations that handle them: token -> stand-in id
@@ -1682,9 +1696,9 @@ __device__ __forceinline__ void tt_flush(TTInfo &ti, uint32_t *hdr_m) {
 }
 
 __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys, uint32_t fake) {
-    uint32_t *words = reinterpret_cast<uint32_t *>(lut.bucket);
+    uint32_t *words = reinterpret_cast<uint32_t *>(lut.m->bucket);
     for (uint32_t i = threadIdx.x; i < kBuckets * kBucketKeys; i += blockDim.x) words[i] = kEmptyPair;
-    uint32_t *iw = reinterpret_cast<uint32_t *>(lut.bidx);
+    uint32_t *iw = reinterpret_cast<uint32_t *>(lut.m->bidx);
     for (uint32_t i = threadIdx.x; i < kBuckets * kBucketKeys / 2; i += blockDim.x) iw[i] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1694,12 +1708,12 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
             const uint32_t a = key >> 16;
             uint32_t b = key & 0xFFFFu;
             if (b == a) b = fake - n_tt++;                                       // (t,t): see tt_rename
-            const uint32_t h = pair_hash(a, b);
+            const uint32_t h = pair_hash(lut.mul, a, b);
             const uint32_t kk = a | (b << 16);
             uint32_t r = 0;                       // first free key of the bucket (selection keeps it within kBucketKeys)
             while (r + 1 < kBucketKeys && words[h * kBucketKeys + r] != kEmptyPair) ++r;
             words[h * kBucketKeys + r] = kk;
-            uint16_t *ix = reinterpret_cast<uint16_t *>(&lut.bidx[h]);
+            uint16_t *ix = reinterpret_cast<uint16_t *>(&lut.m->bidx[h]);
             ix[r] = (uint16_t)j;
         }
     }
@@ -1709,7 +1723,7 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
 // is (first, second) a batch pair?  first may be any raw slot value (a hole or a
 // token with the chunk-end bit never matches), second the id of the next live token
 __device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, uint32_t second) {
-    const auto bk = lut.bucket[pair_hash(first, second)];
+    const auto bk = lut.m->bucket[pair_hash(lut.mul, first, second)];
     const uint32_t kk = first | (second << 16);
 #if MBPE_LUT_KEYS == 2
     return bk.x == kk || bk.y == kk;
@@ -1723,8 +1737,8 @@ __device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, u
 // batch pair, something non-zero otherwise.
 __device__ __forceinline__ uint32_t pair_miss(const BatchLut &lut, uint32_t first, uint32_t second) {
     uint32_t h;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(2531u), "v"(first));
-    const auto bk = lut.bucket[h & (kBuckets - 1u)];
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(lut.mul), "v"(first));
+    const auto bk = lut.m->bucket[h & (kBuckets - 1u)];
     const uint32_t kk = first | (second << 16);
     const uint32_t dx = bk.x ^ kk, dy = bk.y ^ kk;
     uint32_t d = dx < dy ? dx : dy;
@@ -1740,8 +1754,8 @@ __device__ __forceinline__ uint32_t pair_miss(const BatchLut &lut, uint32_t firs
 // compare per key, and the results combine on the scalar unit.
 __device__ __forceinline__ bool pair_hit(const BatchLut &lut, uint32_t first, uint32_t second) {
     uint32_t h;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(2531u), "v"(first));
-    const auto bk = lut.bucket[h & (kBuckets - 1u)];
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(lut.mul), "v"(first));
+    const auto bk = lut.m->bucket[h & (kBuckets - 1u)];
     const uint32_t kk = first | (second << 16);
 #if MBPE_LUT_KEYS == 2
     return bk.x == kk || bk.y == kk;
@@ -1752,16 +1766,16 @@ __device__ __forceinline__ bool pair_hit(const BatchLut &lut, uint32_t first, ui
 
 // index of the pair (only called for pairs that passed pair_test)
 __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, uint32_t second) {
-    const uint32_t h = pair_hash(first, second);
+    const uint32_t h = pair_hash(lut.mul, first, second);
 #if MBPE_LUT_KEYS == 2
-    const uint32_t ix = lut.bidx[h];
+    const uint32_t ix = lut.m->bidx[h];
 #endif
     const uint32_t kk = first | (second << 16);
 #if MBPE_LUT_KEYS == 2
-    return (int)(lut.bucket[h].x == kk ? ix & 0xFFFFu : ix >> 16);
+    return (int)(lut.m->bucket[h].x == kk ? ix & 0xFFFFu : ix >> 16);
 #else
-    const uint4 bk = lut.bucket[h];
-    const uint2 i2 = lut.bidx[h];
+    const uint4 bk = lut.m->bucket[h];
+    const uint2 i2 = lut.m->bidx[h];
     const uint32_t w = (bk.x == kk || bk.y == kk) ? i2.x : i2.y;
     return (int)((bk.x == kk || bk.z == kk) ? w & 0xFFFFu : w >> 16);
 #endif
@@ -1881,7 +1895,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
             for (uint32_t i = 0; i < accepted; ++i) {
                 const uint32_t ai = s_keys[i] >> 16, bi = s_keys[i] & 0xFFFFu;
                 conflict |= (b == ai) || (a == bi);
-                same_bucket += pair_hash(ai, bi) == pair_hash(a, b);
+                same_bucket += pair_hash(kHashMul[0], ai, bi) == pair_hash(kHashMul[0], a, b);
             }
             if (conflict || same_bucket >= kBucketKeys) {       // (a lookup bucket holds kBucketKeys keys)
                 if (tid == 0) { if (conflict) ctl->cut_conflict += 1; else ctl->cut_bucket += 1; }
@@ -1895,6 +1909,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
             bs->eidx[accepted] = cand_idx;
             bs->packed[accepted] = cand;
             bs->maxp[accepted] = 0;
+            bs->hash_mul = kHashMul[0];
             bs->skip_n = 0;                 // (this kernel ends the batch at a dependent pair
             bs->tt_index = kNoTT;           //  and merges a (t,t) pair alone)
             bs->tt_n = 0;
@@ -2011,10 +2026,12 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
     // what the members accepted so far occupy (the independence test of a candidate is then a few LDS reads,
     // whatever the batch size): is a token the FIRST / SECOND element of a member (exact bitmaps), how many
     // members have it there (8-bit counts, ids folded to 15 bits: only the pass-over prediction uses them),
-    // and how many keys every bucket of the kernels' lookup table holds
+    // and how many keys every bucket of the kernels' lookup table holds -- under each of the kHashSeeds hash
+    // multipliers still in the race (small packed counters)
     __shared__ uint32_t set_first[2048], set_second[2048];
     __shared__ uint8_t cnt_first[32768], cnt_second[32768];
-    __shared__ uint8_t bucket_fill[kBuckets];
+    constexpr uint32_t kFillBits = kBucketKeys <= 3 ? 2 : 4, kFillPerWord = 32 / kFillBits;
+    __shared__ uint32_t bucket_fill[kHashSeeds][kBuckets / kFillPerWord];
     const uint32_t tid = threadIdx.x;
     if (attempt > 0 && (ctl->sel_ok || !ctl->sel_retry)) return;
     const uint32_t k0 = ctl->k_done;
@@ -2051,7 +2068,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         reinterpret_cast<uint32_t *>(cnt_first)[i] = 0;
         reinterpret_cast<uint32_t *>(cnt_second)[i] = 0;
     }
-    for (uint32_t i = tid; i < kBuckets / 4u; i += kPickThreads) reinterpret_cast<uint32_t *>(bucket_fill)[i] = 0;
+    for (uint32_t i = tid; i < (uint32_t)kHashSeeds * (kBuckets / kFillPerWord); i += kPickThreads) (&bucket_fill[0][0])[i] = 0;
     __syncthreads();
     // bitonic sort, descending by packed value (unique per pair: a total order)
     for (uint32_t k = 2; k <= n_sort; k <<= 1) {
@@ -2114,6 +2131,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         unsigned long long skip_floor = 0;
         uint32_t n_tt = 0;                          // (t,t) members so far, and the map slots they occupy
         unsigned long long tt_slots[kTTSlots / 64] = {};
+        uint32_t alive = (1u << kHashSeeds) - 1u;   // hash multipliers under which every bucket still holds its keys
         if (tid == 0) bs->tt_index = kNoTT;
         for (; accepted < limit && ci < n_l; ++ci) {
             const unsigned long long cand = sp[ci];
@@ -2122,11 +2140,19 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             const bool tt = a == b && count != 0;      // (t,t): a member like any other once renamed (tt_rename),
             const uint32_t slot = a & (kTTSlots - 1u);                //  while stand-in ids and map slots last
             const bool single = count == 0 || (tt && (n_tt >= tt_max || ((tt_slots[slot >> 6] >> (slot & 63u)) & 1ull)));
-            const uint32_t h = pair_hash(a, tt ? fake_id - n_tt : b);
+            // multipliers under which this key would be the bucket's (kBucketKeys + 1)-th: they drop out if it is accepted
+            const uint32_t b_hash = tt ? fake_id - n_tt : b;
+            uint32_t full = 0;
+#pragma unroll
+            for (int sd = 0; sd < kHashSeeds; ++sd) {
+                const uint32_t h = pair_hash(kHashMul[sd], a, b_hash);
+                const uint32_t f = (bucket_fill[sd][h / kFillPerWord] >> ((h % kFillPerWord) * kFillBits)) & ((1u << kFillBits) - 1u);
+                full |= (f >= kBucketKeys ? 1u : 0u) << sd;
+            }
             if (accepted > 0) {
                 // dependent on an earlier member (c, d): b == c or a == d
                 const bool conf = (((set_first[b >> 5] >> (b & 31u)) | (set_second[a >> 5] >> (a & 31u))) & 1u) != 0u;
-                const uint32_t same = bucket_fill[h];
+                const bool no_bucket = (alive & ~full) == 0u;
                 if (single) { cut = 3u; break; }
                 if (conf && n_skip < (uint32_t)kSkipMax && skip_allowed) {
                     // Depends on an earlier member (shares a token with it the wrong way round): the
@@ -2147,14 +2173,20 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                     skip_floor = fl > skip_floor ? fl : skip_floor;
                     continue;
                 }
-                if (conf || same >= kBucketKeys) { cut = conf ? 1u : 2u; break; }
+                if (conf || no_bucket) { cut = conf ? 1u : 2u; break; }
                 if (cand < skip_floor) { cut = 1u; break; }
             }
             set_first[a >> 5] |= 1u << (a & 31u);
             set_second[b >> 5] |= 1u << (b & 31u);
             if (cnt_first[a & 0x7FFFu] != 0xFFu) cnt_first[a & 0x7FFFu] += 1;
             if (cnt_second[b & 0x7FFFu] != 0xFFu) cnt_second[b & 0x7FFFu] += 1;
-            bucket_fill[h] += 1;
+            alive &= ~full;
+#pragma unroll
+            for (int sd = 0; sd < kHashSeeds; ++sd) {
+                if (!((alive >> sd) & 1u)) continue;
+                const uint32_t h = pair_hash(kHashMul[sd], a, b_hash);
+                bucket_fill[sd][h / kFillPerWord] += 1u << ((h % kFillPerWord) * kFillBits);
+            }
             bs->key[accepted] = key;
             bs->eidx[accepted] = si[ci];
             bs->packed[accepted] = cand;
@@ -2166,7 +2198,10 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             if (single) { cut = 3u; ++ci; break; }
         }
         // (candidates passed over behind the last member do not matter: nothing was chosen after them)
-        if (tid == 0) { bs->skip_n = n_skip; bs->tt_n = n_tt; ctl->n_skipped += n_skip; }
+        if (tid == 0) {
+            bs->skip_n = n_skip; bs->tt_n = n_tt; ctl->n_skipped += n_skip;
+            bs->hash_mul = kHashMul[alive ? (uint32_t)__builtin_ctz(alive) : 0u];
+        }
         if (tid == 0) {
             ctl->batch_n = accepted;
             ctl->commit_n = accepted;
@@ -2460,7 +2495,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
                                                               const RankEdge *re,
                                                               const uint32_t *__restrict__ run_in) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
-    __shared__ BatchLut lut;
+    __shared__ BatchLutMem lut_mem;
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kLutThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
@@ -2473,6 +2508,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
+    BatchLut lut(&lut_mem, bs);
     lut_build(lut, bs, n_keys, idmask - 1u);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
@@ -2705,7 +2741,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                                                                const RankEdge *le, const RankEdge *re,
                                                                uint32_t *hdr_m, const uint32_t *__restrict__ run_in) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
-    __shared__ BatchLut lut;
+    __shared__ BatchLutMem lut_mem;
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kLutThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
@@ -2721,6 +2757,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
+    BatchLut lut(&lut_mem, bs);
     lut_build(lut, bs, n_keys, idmask - 1u);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->marks_all = 1;
@@ -3203,7 +3240,7 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
                                                                   const uint32_t *__restrict__ run_in) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
-    __shared__ BatchLut lut;
+    __shared__ BatchLutMem lut_mem;
     if (ctl->batch_n < 2 || (ctl->fused && ctl->commit_n == ctl->batch_n)) return;
     uint16_t *tok = ctl->cur ? tok1 : tok0;
     const uint32_t n_keys = ctl->commit_n;
@@ -3212,6 +3249,7 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
     const uint32_t X0 = 256u + ctl->k_done;
     const uint32_t n_list = ctl->n_marked;
     const bool marks_all = ctl->marks_all != 0u;
+    BatchLut lut(&lut_mem, bs);
     lut_build(lut, bs, n_keys, idmask - 1u);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     const uint32_t lane = lane_id();

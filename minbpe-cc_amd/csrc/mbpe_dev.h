@@ -175,6 +175,9 @@ struct BatchState {
     uint32_t tt_index;
     uint32_t tt_token;
     uint32_t tt_n;
+    // multiplier of the lookup-table hash for this batch: the selection tries several and keeps one under which no
+    // bucket of the table has to hold a third key (kernels.hip: kHashMul, pair_hash)
+    uint32_t hash_mul;
     // candidates passed over because they depend on an earlier member of the batch (see k_sel_pick)
     uint32_t skip_n;
     uint32_t skip_key[kSkipMax];
