@@ -2116,8 +2116,12 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
     if (limit > max_batch) limit = max_batch;
     if (limit > (uint32_t)kBatchMax) limit = kBatchMax;
     if (limit > adapt) limit = adapt;
-    // the independent prefix (sequential by nature: one thread; everything it looks at is in LDS)
-    if (tid == 0) {
+    // the independent prefix (sequential by nature; everything it looks at is in LDS).  One wave runs it with uniform
+    // control flow: lane s keeps the bucket fills of hash multiplier s, lane 0 does the stores
+    if (tid < (uint32_t)kWave) {
+        const bool l0 = tid == 0;
+        const bool seed_lane = tid < (uint32_t)kHashSeeds;
+        const uint32_t my_mul = kHashMul[tid & 7u];
         uint32_t accepted = 0;
         uint32_t cut = 0;      // 1 conflict, 2 bucket, 3 single
         uint32_t n_skip = 0, ci = 0;
@@ -2142,13 +2146,11 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             const bool single = count == 0 || (tt && (n_tt >= tt_max || ((tt_slots[slot >> 6] >> (slot & 63u)) & 1ull)));
             // multipliers under which this key would be the bucket's (kBucketKeys + 1)-th: they drop out if it is accepted
             const uint32_t b_hash = tt ? fake_id - n_tt : b;
-            uint32_t full = 0;
-#pragma unroll
-            for (int sd = 0; sd < kHashSeeds; ++sd) {
-                const uint32_t h = pair_hash(kHashMul[sd], a, b_hash);
-                const uint32_t f = (bucket_fill[sd][h / kFillPerWord] >> ((h % kFillPerWord) * kFillBits)) & ((1u << kFillBits) - 1u);
-                full |= (f >= kBucketKeys ? 1u : 0u) << sd;
-            }
+            const uint32_t my_h = pair_hash(my_mul, a, b_hash);
+            uint32_t my_f = 0;
+            if (seed_lane)
+                my_f = (bucket_fill[tid][my_h / kFillPerWord] >> ((my_h % kFillPerWord) * kFillBits)) & ((1u << kFillBits) - 1u);
+            const uint32_t full = (uint32_t)__ballot(seed_lane && my_f >= kBucketKeys);
             if (accepted > 0) {
                 // dependent on an earlier member (c, d): b == c or a == d
                 const bool conf = (((set_first[b >> 5] >> (b & 31u)) | (set_second[a >> 5] >> (a & 31u))) & 1u) != 0u;
@@ -2160,9 +2162,11 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                     // time it could be chosen -- normally below the whole batch.  Pass it over;
                     // k_validate checks from the measured deltas that it really fell behind every
                     // member chosen after this point, and cuts the batch here otherwise.
-                    bs->skip_key[n_skip] = key;
-                    bs->skip_pos[n_skip] = accepted;
-                    bs->skip_packed[n_skip] = cand;
+                    if (l0) {
+                        bs->skip_key[n_skip] = key;
+                        bs->skip_pos[n_skip] = accepted;
+                        bs->skip_packed[n_skip] = cand;
+                    }
                     ++n_skip;
                     // (it loses occurrences to every member it depends on: red_q16 is the fraction per such member)
                     const uint32_t n_dep = (uint32_t)cnt_first[b & 0x7FFFu] + cnt_second[a & 0x7FFFu];
@@ -2176,23 +2180,21 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 if (conf || no_bucket) { cut = conf ? 1u : 2u; break; }
                 if (cand < skip_floor) { cut = 1u; break; }
             }
-            set_first[a >> 5] |= 1u << (a & 31u);
-            set_second[b >> 5] |= 1u << (b & 31u);
-            if (cnt_first[a & 0x7FFFu] != 0xFFu) cnt_first[a & 0x7FFFu] += 1;
-            if (cnt_second[b & 0x7FFFu] != 0xFFu) cnt_second[b & 0x7FFFu] += 1;
             alive &= ~full;
-#pragma unroll
-            for (int sd = 0; sd < kHashSeeds; ++sd) {
-                if (!((alive >> sd) & 1u)) continue;
-                const uint32_t h = pair_hash(kHashMul[sd], a, b_hash);
-                bucket_fill[sd][h / kFillPerWord] += 1u << ((h % kFillPerWord) * kFillBits);
+            if (seed_lane && ((alive >> tid) & 1u))
+                bucket_fill[tid][my_h / kFillPerWord] += 1u << ((my_h % kFillPerWord) * kFillBits);
+            if (l0) {
+                set_first[a >> 5] |= 1u << (a & 31u);
+                set_second[b >> 5] |= 1u << (b & 31u);
+                if (cnt_first[a & 0x7FFFu] != 0xFFu) cnt_first[a & 0x7FFFu] += 1;
+                if (cnt_second[b & 0x7FFFu] != 0xFFu) cnt_second[b & 0x7FFFu] += 1;
+                bs->key[accepted] = key;
+                bs->eidx[accepted] = si[ci];
+                bs->packed[accepted] = cand;
+                bs->maxp[accepted] = 0;
+                best[k0 + accepted] = cand;
+                if (tt && n_tt == 0) { bs->tt_index = accepted; bs->tt_token = a; }
             }
-            bs->key[accepted] = key;
-            bs->eidx[accepted] = si[ci];
-            bs->packed[accepted] = cand;
-            bs->maxp[accepted] = 0;
-            best[k0 + accepted] = cand;
-            if (tt && n_tt == 0) { bs->tt_index = accepted; bs->tt_token = a; }
             if (tt) { tt_slots[slot >> 6] |= 1ull << (slot & 63u); ++n_tt; }
             ++accepted;
             if (single) { cut = 3u; ++ci; break; }
