@@ -129,9 +129,11 @@ def cpu_baseline(data, merges, what):
     }
 
 
+COPY_ONLY_GBS = 5100.0        # k_fused_batch with everything but the tile copy compiled out (MBPE_FUSED_DIAG=4): 17.2 GB in 3.37 ms
+ATOMIC_UNIT_GPS = 24.4        # scattered global atomicAdd, 2 active lanes per instruction, any table size up to 256 MB
 FUSED_LIMITER = ("per-match work on top of the pass's copy floor (3.4 ms for 17.2 GB = 0.64 of peak): two scattered global "
                  "atomics per match (the atomic unit does 24 G/s whatever the table size, tools/atomic_footprint.hip) and "
-                 "vector-instruction issue; a pass of up to 1024 merges holds ~3.5e7 matches (DESIGN.md section 4, "
+                 "vector-instruction issue; a pass of up to 1024 merges holds ~5e7 matches: see floor_model (DESIGN.md section 4, "
                  "profiles/r02_fused_ablation.md)")
 
 
@@ -251,6 +253,20 @@ def main():
         pass_bytes = 2.0 * s1["n_slots"]
         limiter = None
     achieved = pass_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # what a fused pass cannot go below: its bytes at the rate of the copy-only build of the same kernel, plus two
+    # scattered global atomics per match at the rate of the unit that executes them (they do not overlap)
+    floor_model = None
+    if roof_name == "k_fused_batch":
+        matches = (s0["n_live"] - s1["n_live"]) / max(n_pass, 1)            # a match removes one token (this rank's shard)
+        stream_ms = pass_bytes / (COPY_ONLY_GBS * 1e9) * 1e3
+        atomics_ms = 2.0 * matches / (ATOMIC_UNIT_GPS * 1e9) * 1e3
+        floor_model = {"stream_ms": stream_ms, "copy_only_GBps": COPY_ONLY_GBS,
+                       "matches_per_launch": matches, "atomics_per_launch": 2.0 * matches,
+                       "atomic_unit_G_per_s": ATOMIC_UNIT_GPS, "atomics_ms": atomics_ms,
+                       "sum_ms": stream_ms + atomics_ms, "measured_ms": avg_ms,
+                       "sources": "copy-only build of the kernel: profiles/r02_fused_ablation.md; atomic unit: "
+                                  "tools/atomic_footprint.hip (flat from 256 KB to 256 MB); additive: "
+                                  "tools/atomic_overlap.hip"}
     # SURVEY.md 8(d) prices a merge step at 2 B x L read + 2 B x L' written; a pass performs
     # merges_per_pass of them on one read: the same sum divided by the measured time
     live_avg = 0.5 * (s0["n_live"] + s1["n_live"])
@@ -374,6 +390,7 @@ def main():
                 "launches": launches,
                 "stream_passes": n_pass,
                 "merges_per_pass": done / max(n_pass, 1),
+                "floor_model": floor_model,
                 "survey_8d_model": {
                     "note": "SURVEY 8(d) counts 2 B x L read + 2 B x L' written PER MERGE; one pass serves "
                             "merges_per_pass merges, so that sum over the pass's merges divided by the pass time "
