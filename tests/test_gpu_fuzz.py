@@ -1,6 +1,6 @@
 """Differential fuzz: random corpora (random alphabets, repeated blocks, long runs, repeated text
 slices, NUL-heavy bytes), random chunkings and random tuning options (batch size, fused pass on/off,
-table layout, selection kernel, compaction, host round trips) -- merges, counts, final stream and
+table layout, selection kernel, compaction, host round trips, chunk-end convention) -- merges, counts, final stream and
 pair table against the CPU oracle."""
 import numpy as np
 import pytest
@@ -12,7 +12,7 @@ from conftest import read_data
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"compact_den": 16, "batch": 64, "multi_merge": 1, "max_batch": 1024, "fused_min": 24,
-            "dense_table": -1, "threshold_select": 1, "sel_cap": 4096}
+            "dense_table": -1, "threshold_select": 1, "sel_cap": 4096, "chunk_barrier": -1}
 
 
 def _case(rng, text):
@@ -38,15 +38,19 @@ def _case(rng, text):
         cuts = np.unique(rng.integers(1, len(data), size=max(len(data) // int(rng.integers(2, 200)), 1)))
         off = np.concatenate([[0], cuts, [len(data)]]).astype(np.uint64)
     vocab = 256 + int(rng.integers(0, 400))
-    opts = {"max_batch": int(rng.choice([1, 2, 3, 7, 16, 64, 128, 256, 512])), "fused_min": int(rng.choice([2, 24, 1000])),
+    opts = {"max_batch": int(rng.choice([1, 2, 3, 7, 16, 64, 128, 256, 512, 1024])), "fused_min": int(rng.choice([2, 24, 1000])),
             "dense_table": int(rng.choice([0, 1])), "threshold_select": int(rng.choice([0, 1])),
             "sel_cap": int(rng.choice([64, 256, 4096])),
             "compact_den": int(rng.choice([0, 2, 8])), "batch": int(rng.choice([1, 3, 64])),
-            "multi_merge": int(rng.choice([0, 1, 1, 1]))}
+            "multi_merge": int(rng.choice([0, 1, 1, 1])),
+            "chunk_barrier": int(rng.choice([-1, 1]))}        # (chunk ends as barrier slots: tests/test_gpu_barrier.py)
     return data, off, vocab, opts
 
 
-@pytest.mark.parametrize("seed", range(4))
+import os
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MBPE_FUZZ_SEEDS", "4"))))
 def test_fuzz_against_oracle(seed):
     text = read_data("shakespeare.txt")
     with mbpe.Trainer(0) as tr:
