@@ -1967,8 +1967,11 @@ __global__ __launch_bounds__(256) void k_sel_scan(PairTable t, DevCtl *ctl, SelL
             __hip_atomic_load(&ctl->sel_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4u * sel_cap) break;
         const uint64_t B64 = (step * kWave + lane) * n_waves + wave;
         const uint32_t B = (uint32_t)B64;
-        const unsigned long long bound = B64 < n_blocks
-            ? __hip_atomic_load(&t.bmax[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        // (the bound of the block's super-block first: 8 KB that stay in the cache, and nearly every super-block
+        //  lies below the threshold -- the candidates sit in the rows of a few frequent first tokens)
+        const bool look = B64 < n_blocks &&
+            __hip_atomic_load(&t.smax[B >> kBlockShift], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= T;
+        const unsigned long long bound = look ? __hip_atomic_load(&t.bmax[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         unsigned long long todo = __ballot(bound >= T);
         if (bounds_only) {
             // looking for a threshold: list the block bounds themselves (8 bytes per 1024 entries)
