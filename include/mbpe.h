@@ -253,6 +253,10 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *                   with a single rank (tests the RCCL binding on one GPU)
  *   "chunk_barrier" chunk ends of a chunked corpus as barrier slots: -1 (default) when vocab_size
  *                   exceeds MBPE_MAX_VOCAB_ENDBIT, 1 always, 0 never; read by mbpe_train_begin
+ *   "first_batches" `first` tie-break only: 1 = pairs whose count no other candidate shares are merged in batches
+ *                   like in lexical mode, a pair with a shared count goes alone after the position tie-break; the
+ *                   run hands over to the one-merge-per-pass loop when most sequences are such single pairs.
+ *                   Default 0 (one merge per pass): same results, and no faster on text.
  *   "conflict_resolution" 1 = lexical tie-break (default), 0 = first (see mbpe_train); before
  *                   mbpe_train_begin only
  *   "time_kernels"  1 = bracket every merge kernel with HIP events on the

@@ -1057,7 +1057,11 @@ __device__ __forceinline__ uint32_t table_lookup(const PairTable &t, uint32_t ke
 
 __global__ __launch_bounds__(256) void k_first_gather(PairTable t, const DevCtl *ctl,
                                                       const unsigned long long *__restrict__ best_ptr,
-                                                      FirstState *fs) {
+                                                      FirstState *fs, int seq) {
+    if (seq) {
+        if (ctl->batch_n != 1 || !ctl->first_tie) return;
+        best_ptr += ctl->k_done;
+    }
     const unsigned long long best = *best_ptr;
     const uint32_t M = (uint32_t)(best >> 32);
     if (M == 0) return;
@@ -1086,13 +1090,19 @@ __global__ __launch_bounds__(256) void k_first_gather(PairTable t, const DevCtl 
 
 template <int MODE>
 __global__ __launch_bounds__(kMergeThreads) void k_first_pos(const uint16_t *__restrict__ tok,
+                                                             const uint16_t *__restrict__ tok_other,
                                                              const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                              PairTable t,
                                                              const unsigned long long *__restrict__ best_ptr,
-                                                             FirstState *fs) {
+                                                             FirstState *fs, const DevCtl *ctl, int seq) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     __shared__ uint32_t bm[kFirstBitmapWords];
+    if (seq) {
+        if (ctl->batch_n != 1 || !ctl->first_tie) return;
+        best_ptr += ctl->k_done;
+        if (ctl->cur) tok = tok_other;
+    }
     if (fs->n_tie <= 1) return;                           // a unique maximum: position does not matter
     const uint32_t M = (uint32_t)(*best_ptr >> 32);
     for (uint32_t i = threadIdx.x; i < kFirstBitmapWords; i += kMergeThreads) bm[i] = fs->bitmap[i];
@@ -1149,9 +1159,13 @@ __global__ __launch_bounds__(kMergeThreads) void k_first_pos(const uint16_t *__r
     }
 }
 
-__global__ __launch_bounds__(256) void k_first_pick(unsigned long long *best_ptr, FirstState *fs) {
+__global__ __launch_bounds__(256) void k_first_pick(unsigned long long *best_ptr, FirstState *fs, const DevCtl *ctl, int seq) {
     __shared__ unsigned long long pk;
     __shared__ uint32_t nt;
+    if (seq) {
+        if (ctl->batch_n != 1 || !ctl->first_tie) return;
+        best_ptr += ctl->k_done;
+    }
     if (threadIdx.x == 0) { pk = fs->pos_key; nt = fs->n_tie; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1812,6 +1826,10 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
     if (limit > max_batch) limit = max_batch;
     if (limit > (uint32_t)kBatchMax) limit = kBatchMax;
     if (ctl->adapt_limit && limit > ctl->adapt_limit) limit = ctl->adapt_limit;
+    if (ctl->first_mode) {          // one pair, and k_first_* look whether another one with its count comes first
+        limit = 1;
+        if (tid == 0) ctl->first_tie = 1;
+    }
     const uint32_t n_blocks = (n + kBlockSize - 1) >> kBlockShift;
     const uint32_t n_super = (n_blocks + kBlockSize - 1) >> kBlockShift;
     auto ld = [](const unsigned long long *p) {
@@ -2131,7 +2149,10 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         // (on text a dependent pair often does NOT fall behind -- few of its occurrences overlap the
         //  earlier pair's -- and a failed pass-over costs a stream pass; after a failure dependent
         //  pairs end the batch again for a while, see k_seq_finish)
+        const bool first_mode = ctl->first_mode != 0;      // (no (t,t) members, no equal counts)
         const bool skip_allowed = ctl->skip_off == 0;
+        if (first_mode) tt_max = 0;
+        if (l0) ctl->first_tie = 0;
         // a passed-over candidate is expected to lose at least this fraction of its count; a member that
         // would still rank behind it ends the batch before the pass instead of failing validation after it
         const unsigned long long red_q16 = ((unsigned long long)MBPE_PRED_NUM * ctl->skip_red_q16) / 4ull;
@@ -2146,7 +2167,15 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             const uint32_t a = key >> 16, b = key & 0xFFFFu;
             const bool tt = a == b && count != 0;      // (t,t): a member like any other once renamed (tt_rename),
             const uint32_t slot = a & (kTTSlots - 1u);                //  while stand-in ids and map slots last
-            const bool single = count == 0 || (tt && (n_tt >= tt_max || ((tt_slots[slot >> 6] >> (slot & 63u)) & 1ull)));
+            bool single = count == 0 || (tt && (n_tt >= tt_max || ((tt_slots[slot >> 6] >> (slot & 63u)) & 1ull)));
+            if (first_mode) {
+                // a count shared with the next candidate (or possibly with one beyond the list) cannot be ranked by
+                // count: such a pair goes alone, with the position tie-break, or ends the batch before it
+                // (behind the end of the list everything is below the gather's threshold T)
+                const bool tie = ci + 1u < n_l ? (uint32_t)(sp[ci + 1u] >> 32) == count : (uint32_t)(T >> 32) >= count;
+                if (tie && accepted > 0) { cut = 1u; break; }
+                if (tie) { single = true; if (l0) ctl->first_tie = 1; }
+            }
             // multipliers under which this key would be the bucket's (kBucketKeys + 1)-th: they drop out if it is accepted
             const uint32_t b_hash = tt ? fake_id - n_tt : b;
             const uint32_t my_h = pair_hash(my_mul, a, b_hash);
@@ -2960,7 +2989,10 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
         if (o > s_run[tid]) s_run[tid] = o;
         __syncthreads();
     }
-    if (tid >= 1 && tid < n && bs->packed[tid] <= s_run[tid - 1]) atomicMin(&s_commit, tid);
+    // (`first` mode: a created pair with the SAME count would be ranked by position, which a batch cannot know)
+    if (tid >= 1 && tid < n &&
+        (ctl->first_mode ? (bs->packed[tid] >> 32) <= (s_run[tid - 1] >> 32) : bs->packed[tid] <= s_run[tid - 1]))
+        atomicMin(&s_commit, tid);
     // candidates the selection passed over because an earlier member eats some of their occurrences:
     // (c, a_i) loses L_i[c], (b_i, d) loses R_i[d].  With those measured, the candidate must rank below
     // every member chosen after it; the batch ends at the first member it still beats.
@@ -2987,8 +3019,9 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
             const unsigned long long frac = cnt0 && n_dep ? ((red << 16) / cnt0) / n_dep : 0ull;
             const unsigned long long later = pack_best((int32_t)(cnt0 > red ? cnt0 - red : 0ull), key);
             uint32_t first = 0xFFFFFFFFu;                       // first member behind it that it still beats
+            const bool by_count = ctl->first_mode != 0;      // (an equal count would be ranked by position)
             for (uint32_t m = pos + lane; m < n; m += kWave)
-                if (bs->packed[m] < later) { first = m; break; }
+                if (by_count ? (bs->packed[m] >> 32) <= (later >> 32) : bs->packed[m] < later) { first = m; break; }
 #pragma unroll
             for (int dd = kWave / 2; dd > 0; dd >>= 1) { const uint32_t o = __shfl_xor(first, dd, kWave); first = o < first ? o : first; }
             if (lane == 0) {
@@ -3693,15 +3726,17 @@ void launch_first_init(hipStream_t s, void *fs) {
 }
 
 void launch_first_tiebreak(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best, void *fs_,
-                           const uint16_t *tok, const TileSum *sums, uint32_t n_tiles, uint32_t endbit, int n_cus) {
+                           const uint16_t *tok, const uint16_t *tok_other, const TileSum *sums, uint32_t n_tiles,
+                           uint32_t endbit, int n_cus, int seq) {
     FirstState *fs = static_cast<FirstState *>(fs_);
     const uint32_t n_blocks = (t.ecap + kBlockSize - 1) >> kBlockShift;
-    hipLaunchKernelGGL(k_first_gather, dim3(blocks_for(n_blocks, 4, 2048)), dim3(256), 0, s, t, ctl, best, fs);
+    hipLaunchKernelGGL(k_first_gather, dim3(blocks_for(n_blocks, 4, 2048)), dim3(256), 0, s, t, ctl, best, fs, seq);
     if (n_tiles) {
         const dim3 grid(tile_grid(n_tiles, n_cus, 8)), block(kMergeThreads);
-        MBPE_BY_MODE(endbit, hipLaunchKernelGGL(k_first_pos<M>, grid, block, 0, s, tok, sums, n_tiles, t, best, fs));
+        MBPE_BY_MODE(endbit, hipLaunchKernelGGL(k_first_pos<M>, grid, block, 0, s, tok, tok_other, sums, n_tiles, t, best, fs,
+                                                ctl, seq));
     }
-    hipLaunchKernelGGL(k_first_pick, dim3(1), dim3(256), 0, s, best, fs);
+    hipLaunchKernelGGL(k_first_pick, dim3(1), dim3(256), 0, s, best, fs, ctl, seq);
 }
 
 void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileSum *sin, TileSum *sout, uint32_t n_tiles,

@@ -127,6 +127,11 @@ struct DevCtl {
     uint32_t skip_failed;       // set by k_validate for k_seq_finish
     uint32_t skip_red_q16;      // what passed-over candidates lost lately, as a fraction of their count (low estimate)
     unsigned long long n_sel_blocks;   // blocks read by the gathers (statistics)
+    // ---- `first` tie-break inside batch sequences ----
+    uint32_t first_mode;        // (host, at begin) ties between equal counts are decided by stream position, not by key:
+                                //   a batch only takes pairs whose counts differ from every other candidate's, and
+                                //   validation treats an equal count like a larger one
+    uint32_t first_tie;         // the selection took ONE pair whose count is shared: k_first_* pick the one that comes first
     uint32_t marks_all;         // the fused pass of this sequence wrote EVERY tile's summary to the side array and set no
                                 //   tile marks (its tiles nearly all change): "every tile is marked"
 
@@ -240,8 +245,11 @@ void launch_argmax(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long 
 // the stream comes first.  fs: first_state_bytes() of device memory, prepared once by launch_first_init.
 size_t first_state_bytes();
 void launch_first_init(hipStream_t s, void *fs);
+// seq != 0: inside a batch sequence: best is the array, the merge index is ctl->k_done, tok / tok_other are token
+// buffers 0 / 1 (ctl->cur picks), and the kernels only work when the selection flagged a tie (ctl->first_tie)
 void launch_first_tiebreak(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best, void *fs,
-                           const uint16_t *tok, const TileSum *sums, uint32_t n_tiles, uint32_t endbit, int n_cus);
+                           const uint16_t *tok, const uint16_t *tok_other, const TileSum *sums, uint32_t n_tiles,
+                           uint32_t endbit, int n_cus, int seq);
 
 // one merge pass over the stream, in place; new summaries of changed tiles go
 // to `side`, their bits are set in `chg` (launch_apply folds them into sums)

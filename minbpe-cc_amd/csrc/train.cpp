@@ -179,6 +179,10 @@ struct mbpe_ctx {
     uint32_t n_valid = 0;        // merges known to be real (table was not empty)
     bool begun = false;
     bool exhausted = false;
+    double merges_per_seq = 0;   // measured over the last group of sequences (0: not known yet)
+    uint32_t first_b = 0, first_s = 0;   // `first` mode: sequences / single-pair sequences seen since begin
+    bool first_legacy = false;   // `first` mode: most batches were single pairs with a shared count (position tie-breaks):
+                                 //   the rest of the run takes the leaner one-merge-per-pass loop
     DevCtl h_ctl = {};
 
     // multi-GPU
@@ -202,6 +206,8 @@ struct mbpe_ctx {
     int64_t opt_dense_table = -1;   // -1 auto / 1: dense pair table when vocab <= 32,768; 0: always hashed
     int hot_possible = 1;           // may a batch of the next group of sequences hold a "frequent" pair (kernels' dc_wanted)?
     int64_t opt_barrier = -1;       // chunk ends as barrier slots: -1 when the ids need 16 bits, 0 never, 1 always
+    int64_t opt_first_batches = 0;  // `first` mode: 1 = pairs whose counts no other pair shares are merged in batches too
+                                    //   (no faster on text: words make chains of pairs with one count)
     int64_t opt_first = 0;          // 1: `first` tie-break (insertion order, PairCount.h:65-74) instead of lexical
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
@@ -491,6 +497,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
         c->opt_first = value == 0;
     }
     else if (n == "chunk_barrier") c->opt_barrier = value < 0 ? -1 : value != 0;       // (read by the next mbpe_train_begin)
+    else if (n == "first_batches") c->opt_first_batches = value != 0;
     else if (n == "sel_cap") c->opt_sel_cap = std::min<int64_t>(std::max<int64_t>(64, value), kSelCap);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
@@ -683,6 +690,9 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     c->k = 0;
     c->n_valid = 0;
     c->exhausted = false;
+    c->first_legacy = false;
+    c->merges_per_seq = 0;
+    c->first_b = c->first_s = 0;
 
     const uint64_t n = c->inert ? 0 : c->n_bytes;
     // barrier layout: written sparsely (byte i -> slot 2i, its barrier or a hole behind it) into a first buffer of
@@ -731,6 +741,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
         DevCtl init = {};
         init.n_live = n + n_bar;         // every corpus byte starts as one live token
         init.n_ranks = (uint32_t)std::max(1, c->n_ranks);
+        init.first_mode = c->opt_first ? 1u : 0u;
         c->h_ctl = init;
         HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl, sizeof(DevCtl), hipMemcpyHostToDevice, c->stream));
     }
@@ -794,8 +805,8 @@ static int begin_finish(mbpe_ctx *c) {
     launch_table_init(c->stream, c->xb0, c->tab, c->ctl);
     launch_argmax(c->stream, c->tab, c->ctl, c->best, use_hier(c));
     if (c->opt_first)
-        launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best, c->first_state, c->tok[c->cur], c->sums, c->n_tiles,
-                              endbit, c->n_cus);
+        launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best, c->first_state, c->tok[c->cur], nullptr, c->sums, c->n_tiles,
+                              endbit, c->n_cus, 0);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     int rc = sync_ctl(c);
     if (rc != MBPE_OK) return rc;
@@ -834,8 +845,8 @@ static void step_finish(mbpe_ctx *c) {
     if (multi) launch_compose_edges(c->stream, c->xb, c->rank, c->n_ranks, c->d_left, c->d_right);
     launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1, use_hier(c));
     if (c->opt_first)
-        launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best + c->k + 1, c->first_state, c->tok[c->cur], c->sums,
-                              c->n_tiles, endbit_of(c), c->n_cus);
+        launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best + c->k + 1, c->first_state, c->tok[c->cur], nullptr, c->sums,
+                              c->n_tiles, endbit_of(c), c->n_cus, 0);
     c->k++;
 }
 
@@ -849,8 +860,11 @@ static size_t step_exchange_words(const mbpe_ctx *c) { return exchange_words(c, 
 // The merge counter lives on the device (ctl->k_done); the host only keeps an
 // upper bound (k_upper) between synchronisations.
 
-// (`first` mode decides every merge by stream position: one merge per pass)
-static inline bool use_batches(const mbpe_ctx *c) { return c->opt_multi_merge != 0 && !c->opt_first; }
+// (`first` mode decides between equal counts by stream position: batches only hold pairs whose counts nothing else
+//  shares -- k_sel_pick, k_validate -- and a pair with a shared count goes alone, after the position tie-break)
+static inline bool use_batches(const mbpe_ctx *c) {
+    return c->opt_multi_merge != 0 && (!c->opt_first || (c->opt_first_batches && !c->first_legacy));
+}
 
 static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exchange
     const uint32_t endbit = endbit_of(c);
@@ -859,6 +873,9 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best,
                         c->n_target, (uint32_t)c->opt_max_batch, (uint32_t)c->opt_fused_min, c->n_cus,
                         std::max(1, c->n_ranks), endbit, (uint32_t)c->opt_sel_cap);
+    if (c->opt_first)
+        launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best, c->first_state, c->tok[0], c->tok[1], c->sums, c->n_tiles,
+                              endbit, c->n_cus, 1);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     // (the live token buffer is ctl->cur: a fused pass flips it without the host knowing)
     launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
@@ -985,10 +1002,14 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
             }
         }
         c->k_upper = c->k;
-        const uint32_t batches_before = c->h_ctl.n_batches;
+        const uint32_t batches_before = c->h_ctl.n_batches, singles_before = c->h_ctl.cut_single;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         uint32_t launched = 0;
-        for (uint32_t g = 0; g < group && c->k_upper < target; ++g, ++launched) {
+        // (sequences past the target do nothing on the device -- ctl->k_limit -- but cost their launches: enqueue
+        //  as many as the last group's merges per sequence say are needed; before that is known, as many as are
+        //  needed if every one merged max_batch pairs)
+        for (uint32_t g = 0; g < group && (c->merges_per_seq > 0 ? c->k + g * c->merges_per_seq < target : c->k_upper < target);
+             ++g, ++launched) {
             seq_stage_a(c, c->opt_time_kernels ? (int)g : -1);
             if (is_multi(c)) {
                 int rc = comm_allreduce(c, c->xb, exchange_words(c, 256 + std::min<uint32_t>(
@@ -1049,6 +1070,26 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
         if (rc != MBPE_OK) return rc;
         if (c->k == before) break;      // nothing left to merge
         seqs_left -= launched;
+        c->merges_per_seq = std::max(1.0, (double)(c->k - before) / std::max(1u, launched));
+        if (c->opt_first && c->k < c->n_target) {
+            // `first` mode on data full of equal counts: nearly every sequence is one pair plus the position
+            // tie-break, which the one-merge-per-pass loop does with fewer kernels.  Hand over: best[k] = the next
+            // pair, chosen as that loop's step_finish would have
+            c->first_b += c->h_ctl.n_batches - batches_before;
+            c->first_s += c->h_ctl.cut_single - singles_before;
+            if (c->first_b >= 32) {
+                const bool hand_over = 2 * c->first_s > c->first_b;
+                c->first_b = c->first_s = 0;
+                if (!hand_over) continue;
+                c->first_legacy = true;
+                HIPCHK(hipMemsetAsync(c->best + c->k, 0, 8, c->stream));
+                launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k, use_hier(c));
+                launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best + c->k, c->first_state, c->tok[c->cur], nullptr,
+                                      c->sums, c->n_tiles, endbit_of(c), c->n_cus, 0);
+                HIPCHK(hipStreamSynchronize(c->stream));
+                break;
+            }
+        }
     }
     if (steps_done_out) *steps_done_out = c->k - start;
     return MBPE_OK;
@@ -1084,8 +1125,14 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
         c->pending = 2;
         return MBPE_NEED_EXCHANGE;
     }
-    if (use_batches(c)) return train_steps_batched(c, n_steps, steps_done_out);
     uint32_t done = 0;
+    if (use_batches(c)) {
+        int rc = train_steps_batched(c, n_steps, &done);
+        if (rc != MBPE_OK || use_batches(c) || done >= n_steps) {      // (use_batches turns false when `first` mode hands over)
+            if (steps_done_out) *steps_done_out = done;
+            return rc;
+        }
+    }
     while (done < n_steps && c->k < c->n_target && !c->exhausted) {
         uint32_t batch = std::min<uint32_t>({(uint32_t)c->opt_batch, n_steps - done, c->n_target - c->k});
         int rc = before_batch(c, batch);   // pair-table headroom (h_ctl.n_entries is exact here)

@@ -102,14 +102,21 @@ def test_train_golden_model_bytes(tr, name):
 FIRST_GOLDENS = sorted(k for k, v in INDEX.items() if v["mode"] == "first")
 
 
+# first_batches 1: pairs whose count no other candidate shares are merged in batches (position tie-breaks only where
+# counts are equal); 0, the default: one merge per pass
+@pytest.mark.parametrize("first_batches", [0, 1])
 @pytest.mark.parametrize("name", FIRST_GOLDENS)
-def test_train_first_mode_golden_model_bytes(tr, name):
+def test_train_first_mode_golden_model_bytes(tr, name, first_batches):
     # the reference CLI's default tie-break (PairCountInsertOrder), on the device
     meta = INDEX[name]
     data = _input(meta["input"])
     enc = meta["encoder"]
     off = None if enc == "basic" else mbpe.presplit(O.PATTERNS[enc], data)
-    merges, counts, stats = tr.train(data, meta["vocab"], off, conflict_resolution=0)
+    tr.set_option("first_batches", first_batches)
+    try:
+        merges, counts, stats = tr.train(data, meta["vocab"], off, conflict_resolution=0)
+    finally:
+        _defaults(tr)
     assert O.model_bytes(O.PATTERNS[enc], merges) == read_golden(name + ".model")
     want_m, want_c = O.train(data, meta["vocab"], off, mode=O.FIRST)
     assert counts.tolist() == want_c.tolist()
@@ -128,8 +135,9 @@ def test_train_first_mode_kats(tr):
         assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
+@pytest.mark.parametrize("first_batches", [0, 1])
 @pytest.mark.parametrize("seed", range(6))
-def test_train_first_mode_fuzz(tr, seed):
+def test_train_first_mode_fuzz(tr, seed, first_batches):
     """Tie-heavy inputs (small alphabets, low counts) against the oracle's rebuilt-table first mode: both
     table layouts, chunked and not, holes and compactions in the stream."""
     rng = np.random.default_rng(1000 + seed)
@@ -140,12 +148,56 @@ def test_train_first_mode_fuzz(tr, seed):
     want_m, want_c = O.train(data, vocab, off, mode=O.FIRST)
     tr.set_option("dense_table", seed % 3 != 0)
     tr.set_option("compact_den", 40 if seed % 2 else 16)
+    tr.set_option("first_batches", first_batches)
     try:
         m, c, _ = tr.train(data, vocab, off, conflict_resolution=0)
     finally:
-        tr.set_option("dense_table", -1)
-        tr.set_option("compact_den", 16)
+        _defaults(tr)
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
+def _zipf_words(seed, n_words, vocab=3000):
+    """Words of random letters with Zipf frequencies: pair counts spread over orders of magnitude, ties only inside
+    frequent words (the tokens of a word that occurs nowhere else share its count)."""
+    rng = np.random.default_rng(seed)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) + b" " for _ in range(vocab)]
+    w = 1.0 / np.arange(1, vocab + 1) ** 1.07
+    idx = rng.choice(vocab, size=n_words, p=w / w.sum())
+    return np.frombuffer(b"".join(words[i] for i in idx), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("chunked", [False, True])
+def test_first_mode_batches_on_word_text(tr, chunked):
+    """`first` with batches on text-like data (1 MB, 1,000 merges): several merges per pass between the tied ones,
+    same merges and counts as the oracle's rebuilt-table loop, and the same final stream and pair table."""
+    data = _zipf_words(5, 160000)
+    off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data) if chunked else None
+    vocab = 256 + 1000
+    want_m, want_c = O.train(data, vocab, off, mode=O.FIRST)
+    tr.set_option("first_batches", 1)
+    try:
+        tr.load_corpus(data, off)
+        tr.set_option("conflict_resolution", 0)
+        tr.train_begin(vocab)
+        done = tr.train_steps(40)                   # (before the run may hand over to the one-merge-per-pass loop)
+        st = tr.stats()
+        done += tr.train_steps(vocab - 256 - 40)
+        m, c = tr.train_result()
+        toks = tr.stream()[0]
+        table = {k: v for k, v in tr.pairs_dict().items() if v}
+    finally:
+        tr.load_corpus(data[:2])                    # (the tie-break can only be changed between trainings)
+        tr.set_option("conflict_resolution", 1)
+        _defaults(tr)
+    assert done == len(want_m)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+    assert st["n_batches"] < 40                     # batches were formed
+    ost = O.State(data, off)
+    for i, (a, b) in enumerate(want_m):
+        ost.merge(int(a), int(b), 256 + i)
+    assert np.array_equal(toks, ost.stream()[0])
+    assert table == {k: v for k, v in ost.table_dict().items() if v}
+    ost.close()
 
 
 def test_pair_count_rollback_paths(tr):
@@ -200,7 +252,7 @@ def test_train_tiny_inputs(tr, data, vocab):
 
 
 DEFAULTS = {"compact_den": 16, "batch": 64, "multi_merge": 1, "max_batch": 1024, "fused_min": 24, "hier_argmax": -1,
-            "dense_table": -1, "threshold_select": 1, "sel_cap": 4096, "chunk_barrier": -1}
+            "dense_table": -1, "threshold_select": 1, "sel_cap": 4096, "chunk_barrier": -1, "first_batches": 0}
 
 
 def _defaults(tr):
