@@ -154,3 +154,17 @@ def test_vocab_limits_chunked(tr):
         _defaults(tr)
     tr.train_begin(65518)
     assert tr.train_steps(5) == 5
+
+
+@pytest.mark.parametrize("data,cuts", [(b"", []), (b"a", []), (b"ab", [1]), (b"abab", [2]), (b"aaaa", [1, 2, 3]),
+                                       (b"\x00123abcabc", [4]), (b"abcabcabc" * 100, [3, 6, 9, 450, 451])])
+def test_tiny_and_degenerate_chunkings_barrier(tr, data, cuts):
+    off = np.array([0] + cuts + [len(data)], dtype=np.uint64) if len(data) else np.array([0], dtype=np.uint64)
+    vocab = 256 + 8
+    want_m, want_c = O.train(data, vocab, off)
+    tr.set_option("chunk_barrier", 1)
+    try:
+        m, c, st = tr.train_lexical(np.frombuffer(data, dtype=np.uint8), vocab, off)
+    finally:
+        _defaults(tr)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
