@@ -595,3 +595,63 @@ def test_large_corpus_properties(tr):
     for k, (a, b) in enumerate(m):
         hist[256 + k] = hist[int(a)] + hist[int(b)]
     assert np.array_equal(occ @ hist, np.bincount(data, minlength=256).astype(np.int64))
+
+
+# For every hash multiplier of the batch lookup table (kernels.hip: kHashMul, 8192 buckets of two keys) three byte
+# pairs that fall into ONE bucket under it -- six distinct bytes each, all 48 distinct: independent of each other.
+_COLLIDING = [((1, 2), (43, 180), (60, 57)), ((3, 4), (22, 255), (71, 40)), ((5, 89), (54, 98), (103, 107)),
+              ((6, 7), (29, 20), (52, 33)), ((9, 181), (16, 106), (23, 31)), ((8, 226), (10, 196), (12, 166)),
+              ((11, 62), (34, 159), (90, 39)), ((13, 17), (41, 109), (69, 201))]
+_HASH_MUL = [2531, 40503, 10007, 60493, 25013, 7919, 52361, 33391]
+
+
+def test_colliding_triples_really_collide():
+    for mul, triple in zip(_HASH_MUL, _COLLIDING):
+        assert len({(b * mul + a) % 8192 for a, b in triple}) == 1
+
+
+@pytest.mark.parametrize("n_triples", [1, 3, 7, 8])
+def test_batch_lookup_switches_hash_multiplier(tr, n_triples):
+    """The top pairs of the corpus are chosen so that, rank after rank, the third key of a bucket appears under the
+    first n_triples hash multipliers: the selection has to drop those and the stream kernels run with another one
+    (all eight used up: the batch ends there).  Merges, counts, stream and pair table against the oracle."""
+    used = {x for t in _COLLIDING for p in t for x in p}
+    seps = [x for x in range(1, 256) if x not in used]
+    rng = np.random.default_rng(11)
+    parts = []
+    rank = 0
+    for t in _COLLIDING[:n_triples]:
+        for a, b in t:
+            n = 4000 - 7 * rank                       # distinct, descending counts: the rank order is fixed
+            rank += 1
+            s = rng.choice(seps, size=n)
+            blk = np.empty((n, 3), dtype=np.uint8)
+            blk[:, 0], blk[:, 1], blk[:, 2] = a, b, s
+            parts.append(blk.reshape(-1))
+    data = np.concatenate(parts)
+    vocab = 256 + 3 * n_triples + 20
+    want_m, want_c = O.train(data, vocab)
+    assert [tuple(x) for x in want_m[:3 * n_triples].tolist()] == [p for t in _COLLIDING[:n_triples] for p in t]
+    tr.set_option("fused_min", 2)
+    try:
+        tr.load_corpus(data)
+        tr.train_begin(vocab)
+        first = tr.train_sequences(1)
+        st = tr.stats()
+        tr.train_steps(vocab - 256 - first)
+        m, c = tr.train_result()
+        toks = tr.stream()[0]
+        table = {k: v for k, v in tr.pairs_dict().items() if v}
+    finally:
+        _defaults(tr)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+    if n_triples < 8:
+        assert first >= 3 * n_triples and st["cut_bucket"] == 0      # one batch held them all, under a later multiplier
+    else:
+        assert first == 23 and st["cut_bucket"] == 1                 # the 24th pair has no multiplier left
+    ost = O.State(data, None)
+    for i, (a, b) in enumerate(want_m):
+        ost.merge(int(a), int(b), 256 + i)
+    assert np.array_equal(toks, ost.stream()[0])
+    assert table == {k: v for k, v in ost.table_dict().items() if v}
+    ost.close()
