@@ -3492,25 +3492,50 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_scan_final(const TileSum 
     }
 }
 
+// A tile's live tokens go to dst[offsets[tile] ..): staged in LDS at the destination's alignment within a 16-byte
+// vector, so that the body leaves as whole aligned vectors (one per lane) and only the ragged ends, which neighbouring
+// tiles complete, as single 2-byte stores.
 __global__ __launch_bounds__(kMergeThreads) void k_compact_scatter(const uint16_t *__restrict__ src,
                                                                    const TileSum *__restrict__ sums,
                                                                    const unsigned long long *__restrict__ offsets,
                                                                    uint32_t n_tiles, uint16_t *__restrict__ dst) {
+    __shared__ __attribute__((aligned(16))) uint16_t stage[kMergeThreads / kWave][kTile + 16];
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
+    const uint32_t lane = lane_id();
+    uint16_t *st = stage[threadIdx.x / kWave];
     for (uint32_t tile = blockIdx.x * waves_per_block + threadIdx.x / kWave; tile < n_tiles; tile += n_waves) {
-        if (sums[tile].n_live == 0) continue;
-        const uint4 q = reinterpret_cast<const uint4 *>(src)[(uint64_t)tile * kWave + lane_id()];
+        const uint32_t total = sums[tile].n_live;
+        if (total == 0) continue;
+        const uint4 q = reinterpret_cast<const uint4 *>(src)[(uint64_t)tile * kWave + lane];
         uint32_t s[8];
         unpack8(q, s);
         uint32_t cnt = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) cnt += s[j] != kHole;
         const uint32_t excl = wave_incl_scan(cnt) - cnt;
-        uint16_t *o = dst + offsets[tile] + excl;
+        const unsigned long long d0 = offsets[tile];
+        const uint32_t sh = (uint32_t)(d0 & 7ull);
+        uint32_t at = sh + excl;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (s[j] != kHole) *o++ = (uint16_t)s[j];
+            if (s[j] != kHole) st[at++] = (uint16_t)s[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // staged slot i is destination slot (d0 - sh) + i: vector v of the stage is an aligned vector of dst
+        uint16_t *base = dst + (d0 - sh);
+        const uint32_t end = sh + total;                         // staged slots [sh, end)
+        const uint32_t v_first = sh ? 1u : 0u, v_last = end / 8u;       // whole vectors [v_first, v_last)
+        for (uint32_t v = v_first + lane; v < v_last; v += kWave)
+            reinterpret_cast<uint4 *>(base)[v] = reinterpret_cast<const uint4 *>(st)[v];
+        if (v_last < v_first) {                                  // everything inside one vector, open at both ends
+            if (lane < total) base[sh + lane] = st[sh + lane];
+        } else {
+            if (sh && lane < 8u - sh) base[sh + lane] = st[sh + lane];                  // head, up to the first boundary
+            if (lane < end - v_last * 8u) base[v_last * 8u + lane] = st[v_last * 8u + lane];   // tail
+        }
+        __builtin_amdgcn_wave_barrier();                         // (the stage is reused by the wave's next tile)
     }
 }
 
