@@ -885,7 +885,29 @@ __global__ __launch_bounds__(kMergeThreads) void k_summarize(const uint16_t *__r
         const uint4 q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kWave + lane_id()];
         uint32_t s[8];
         unpack8(q, s);
-        const uint4 sum = wave_summary(s);
+        uint4 sum;
+        bool live = true;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) live = live && s[j] != kHole;
+        if (__ballot(!live) == 0ull) {
+            // no hole in the tile (fresh from k_widen or from a compaction): the ends are where they are, and the
+            // trailing run of tokens equal to the last one is 512 minus the position of the last token that differs
+            const uint32_t lane = lane_id();
+            const uint32_t t0 = rlane(s[7], kWave - 1);
+            uint32_t last_diff = 0;                        // 1 + index (in the lane) of the last slot that differs from t0
+#pragma unroll
+            for (int j = 0; j < 8; ++j) last_diff = s[j] != t0 ? (uint32_t)j + 1u : last_diff;
+            const unsigned long long dm = __ballot(last_diff != 0u);
+            uint32_t run = kTile;
+            if (dm) {
+                const uint32_t hl = 63u - (uint32_t)__builtin_clzll(dm);
+                run = kTile - (hl * 8u + rlane(last_diff, hl));
+            }
+            sum = sum_to_u4(rlane(s[0], 0), rlane(s[1], 0), rlane(s[6], kWave - 1), t0, kTile, run);
+            (void)lane;
+        } else {
+            sum = wave_summary(s);
+        }
         if (lane_id() == 0) reinterpret_cast<uint4 *>(sums)[tile] = sum;
     }
 }
