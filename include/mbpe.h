@@ -235,7 +235,7 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
 
 /* Tuning knobs (tests force rare paths with them).
  *   "compact_den"   compact when holes * den >= slots (default 16; 0 = never)
- *   "batch"         sequences (or single merges) per host round trip (default 64)
+ *   "batch"         sequences (or single merges) per host round trip (default 16)
  *   "multi_merge"   1 = several independent merges per stream pass (default), 0 = one
  *   "max_batch"     most merges one pass may take (default and limit 1024)
  *   "fused_min"     batches of at least this many pairs read the stream once and write

@@ -194,7 +194,7 @@ struct mbpe_ctx {
 
     // options
     int64_t opt_compact_den = 16;
-    int64_t opt_batch = 64;
+    int64_t opt_batch = 16;         // sequences between two host synchronisations (compaction is decided there)
     int64_t opt_time_kernels = 0;   // HIP events around every merge kernel (bench.py)
     int64_t opt_force_exchange = 0; // run the multi-rank path (edges, exchange) even with one rank
     int64_t opt_hier_argmax = -1;   // -1 auto (by table size), 0 full scan, 1 hierarchical

@@ -11,7 +11,7 @@ from conftest import read_data
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = {"compact_den": 16, "batch": 64, "multi_merge": 1, "max_batch": 1024, "fused_min": 24,
+DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 1024, "fused_min": 24,
             "dense_table": -1, "threshold_select": 1, "sel_cap": 4096, "chunk_barrier": -1}
 
 

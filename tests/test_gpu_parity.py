@@ -251,7 +251,7 @@ def test_train_tiny_inputs(tr, data, vocab):
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
-DEFAULTS = {"compact_den": 16, "batch": 64, "multi_merge": 1, "max_batch": 1024, "fused_min": 24, "hier_argmax": -1,
+DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 1024, "fused_min": 24, "hier_argmax": -1,
             "dense_table": -1, "threshold_select": 1, "sel_cap": 4096, "chunk_barrier": -1, "first_batches": 0}
 
 
@@ -347,7 +347,7 @@ def test_train_options_do_not_change_results(tr, batch, den):
     try:
         m, c, st = tr.train_lexical(data, 400)
     finally:
-        tr.set_option("batch", 64)
+        tr.set_option("batch", 16)
         tr.set_option("compact_den", 16)
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
     if den == 1:
@@ -405,7 +405,7 @@ def test_argmax_variants_agree(tr, hier):
         m, c, _ = tr.train_lexical(data, 3000)
     finally:
         tr.set_option("hier_argmax", -1)
-        tr.set_option("batch", 64)
+        tr.set_option("batch", 16)
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
