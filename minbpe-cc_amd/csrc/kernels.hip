@@ -3147,20 +3147,22 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
 // A new token's pairs are plain stores; their argmax bounds are raised once per wave.
 constexpr int kApplyTile = 64;
 
-__device__ __forceinline__ void dense_insert_run(const PairTable &t, bool active, uint32_t e, uint32_t key,
-                                                 uint32_t count, uint32_t &n_new) {
-    // lanes hold neighbouring cells e of one row (one to three tiles); active lanes insert count;
-    // n_new (uniform) collects the number of inserts -- one atomic on ctl->n_entries per wave, not per
-    // call: that counter is a single address
+// Inserting runs of neighbouring cells: dense_insert_store writes the cells (new pairs: plain stores) and hands back each
+// lane's packed value; the caller keeps a running maximum per tile and raises the argmax bounds once at the end
+// (dense_raise_bounds) -- reading a bound before every run would be a chain of dependent loads.  n_new (uniform)
+// collects the number of inserts: one atomic on ctl->n_entries per wave, that counter being a single address.
+__device__ __forceinline__ unsigned long long dense_insert_store(const PairTable &t, bool active, uint32_t e, uint32_t key,
+                                                                 uint32_t count, uint32_t &n_new) {
     if (active) t.cells[e] = kPresent | count;
-    unsigned long long m = __ballot(active);
-    if (!m) return;
-    n_new += (uint32_t)__popcll(m);
-    const unsigned long long p = active ? pack_best((int32_t)count, key) : 0ull;
-    const uint32_t blk = e >> kBlockShift;
-    while (m) {                                   // one bound update per tile touched
+    n_new += (uint32_t)__popcll(__ballot(active));
+    return active ? pack_best((int32_t)count, key) : 0ull;
+}
+__device__ __forceinline__ void dense_raise_bounds(const PairTable &t, unsigned long long p, uint32_t blk) {
+    // p: this lane's maximum (0: none) among the cells it inserted into tile blk; one bound update per tile touched
+    unsigned long long m = __ballot(p != 0ull);
+    while (m) {
         const uint32_t blk0 = rfl(__shfl(blk, (uint32_t)__builtin_ctzll(m), kWave));
-        const bool mine = active && blk == blk0;
+        const bool mine = p != 0ull && blk == blk0;
         const unsigned long long pm = wave_max_u64(mine ? p : 0ull);
         if (lane_id() == 0) {
             if (pm > t.bmax[blk0]) atomicMax(&t.bmax[blk0], pm);
@@ -3173,6 +3175,7 @@ __device__ __forceinline__ void dense_insert_run(const PairTable &t, bool active
 __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *ctl, const BatchState *bs,
                                                            uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR) {
     __shared__ uint2 tile[kApplyTile][kApplyTile + 1];
+    __shared__ uint32_t keys[kApplyTile];           // bs->key[j0 ..]
     const uint32_t n = ctl->batch_n;
     if (n < 2) return;
     const uint32_t commit = ctl->commit_n;
@@ -3181,6 +3184,7 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
     const uint32_t x0 = (blockIdx.x / j_parts) * kApplyTile, j0 = (blockIdx.x % j_parts) * kApplyTile;
     const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
     if (x0 < X0 && j0 < n) {
+        if (threadIdx.x < (uint32_t)kApplyTile) keys[threadIdx.x] = j0 + threadIdx.x < n ? bs->key[j0 + threadIdx.x] : 0u;
         // load (and clear) the deltas of ids x0.. and pairs j0..: rows along j are contiguous in LR
         for (uint32_t r = wave; r < (uint32_t)kApplyTile; r += 256 / kWave) {
             const uint32_t x = x0 + r, j = j0 + lane;
@@ -3200,7 +3204,9 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
         uint32_t err = 0, n_new = 0;
         // lanes along j: left neighbours x
         const uint32_t jl = j0 + lane;
-        const uint32_t a = jl < n ? bs->key[jl] >> 16 : 0u;
+        const uint32_t a = keys[lane] >> 16;
+        // (new pairs (x, X_j): this lane's column X0 + jl, rows x0 .. x0 + 63 = two rows of tiles)
+        unsigned long long accL[2] = {0ull, 0ull};
         for (uint32_t r0 = 0; r0 < kRows; r0 += 4) {
             uint32_t l[4], old[4];
 #pragma unroll
@@ -3213,14 +3219,23 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t r = wave + (r0 + u) * (256 / kWave), x = x0 + r;
-                dense_insert_run(t, l[u] != 0u, dense_index(t, (x << 16) | (X0 + jl)), (x << 16) | (X0 + jl), l[u], n_new);
+                const unsigned long long p = dense_insert_store(t, l[u] != 0u, dense_index(t, (x << 16) | (X0 + jl)),
+                                                                (x << 16) | (X0 + jl), l[u], n_new);
+                const uint32_t rb = r >> 5;                 // (x0 is a multiple of 64)
+                accL[rb] = p > accL[rb] ? p : accL[rb];
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u)
                 err |= !(old[u] & kPresent) ? kErrMissingPair : ((old[u] & ~kPresent) < l[u] ? kErrNegCount : 0u);
         }
+#pragma unroll
+        for (uint32_t rb = 0; rb < 2; ++rb)
+            dense_raise_bounds(t, accL[rb], dense_index(t, ((x0 + 32u * rb) << 16) | (X0 + jl)) >> kBlockShift);
         // lanes along x: right neighbours x
         const uint32_t xr = x0 + lane;
+        // (new pairs (X_j, x): rows X0 + j0 .. + 63 = up to three rows of tiles, this lane's column xr)
+        unsigned long long accR[3] = {0ull, 0ull, 0ull};
+        const uint32_t Xrow0 = (X0 + j0) >> 5;
         for (uint32_t c0 = 0; c0 < kRows; c0 += 4) {
             uint32_t rr[4], old[4];
 #pragma unroll
@@ -3228,17 +3243,25 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
                 const uint32_t c = wave + (c0 + u) * (256 / kWave), j = j0 + c;
                 rr[u] = j < n ? tile[lane][c].y : 0u;
                 old[u] = kPresent | rr[u];
-                if (rr[u]) old[u] = atomicAdd(&t.cells[dense_index(t, ((bs->key[j] & 0xFFFFu) << 16) | xr)], 0u - rr[u]);
+                if (rr[u]) old[u] = atomicAdd(&t.cells[dense_index(t, ((keys[c] & 0xFFFFu) << 16) | xr)], 0u - rr[u]);
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t c = wave + (c0 + u) * (256 / kWave), X = X0 + j0 + c;
-                dense_insert_run(t, rr[u] != 0u, dense_index(t, (X << 16) | xr), (X << 16) | xr, rr[u], n_new);
+                const unsigned long long p = dense_insert_store(t, rr[u] != 0u, dense_index(t, (X << 16) | xr), (X << 16) | xr,
+                                                                rr[u], n_new);
+                const uint32_t rb = (X >> 5) - Xrow0;       // 0, 1 or 2
+                if (rb == 0) accR[0] = p > accR[0] ? p : accR[0];
+                else if (rb == 1) accR[1] = p > accR[1] ? p : accR[1];
+                else accR[2] = p > accR[2] ? p : accR[2];
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u)
                 err |= !(old[u] & kPresent) ? kErrMissingPair : ((old[u] & ~kPresent) < rr[u] ? kErrNegCount : 0u);
         }
+#pragma unroll
+        for (uint32_t rb = 0; rb < 3; ++rb)
+            dense_raise_bounds(t, accR[rb], dense_index(t, (((Xrow0 + rb) << 5) << 16) | xr) >> kBlockShift);
         if (err) atomicOr(&ctl->err, err);
         if (lane == 0 && n_new) atomicAdd(&ctl->n_entries, n_new);
     }
