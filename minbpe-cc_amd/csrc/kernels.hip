@@ -2075,6 +2075,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
     __shared__ uint8_t cnt_first[32768], cnt_second[32768];
     constexpr uint32_t kFillBits = kBucketKeys <= 3 ? 2 : 4, kFillPerWord = 32 / kFillBits;
     __shared__ uint32_t bucket_fill[kHashSeeds][kBuckets / kFillPerWord];
+    __shared__ uint16_t acc_ci[kBatchMax];         // list position of every accepted member (written out after the walk)
     const uint32_t tid = threadIdx.x;
     if (attempt > 0 && (ctl->sel_ok || !ctl->sel_retry)) return;
     const uint32_t k0 = ctl->k_done;
@@ -2183,8 +2184,10 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         unsigned long long tt_slots[kTTSlots / 64] = {};
         uint32_t alive = (1u << kHashSeeds) - 1u;   // hash multipliers under which every bucket still holds its keys
         if (tid == 0) bs->tt_index = kNoTT;
+        unsigned long long cand_next = n_l ? sp[0] : 0ull;         // (the next candidate is read one step ahead)
         for (; accepted < limit && ci < n_l; ++ci) {
-            const unsigned long long cand = sp[ci];
+            const unsigned long long cand = cand_next;
+            cand_next = sp[ci + 1u < n_l ? ci + 1u : ci];
             const uint32_t count = (uint32_t)(cand >> 32), key = ~(uint32_t)cand;
             const uint32_t a = key >> 16, b = key & 0xFFFFu;
             const bool tt = a == b && count != 0;      // (t,t): a member like any other once renamed (tt_rename),
@@ -2194,7 +2197,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 // a count shared with the next candidate (or possibly with one beyond the list) cannot be ranked by
                 // count: such a pair goes alone, with the position tie-break, or ends the batch before it
                 // (behind the end of the list everything is below the gather's threshold T)
-                const bool tie = ci + 1u < n_l ? (uint32_t)(sp[ci + 1u] >> 32) == count : (uint32_t)(T >> 32) >= count;
+                const bool tie = ci + 1u < n_l ? (uint32_t)(cand_next >> 32) == count : (uint32_t)(T >> 32) >= count;
                 if (tie && accepted > 0) { cut = 1u; break; }
                 if (tie) { single = true; if (l0) ctl->first_tie = 1; }
             }
@@ -2242,16 +2245,22 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 set_second[b >> 5] |= 1u << (b & 31u);
                 if (cnt_first[a & 0x7FFFu] != 0xFFu) cnt_first[a & 0x7FFFu] += 1;
                 if (cnt_second[b & 0x7FFFu] != 0xFFu) cnt_second[b & 0x7FFFu] += 1;
-                bs->key[accepted] = key;
-                bs->eidx[accepted] = si[ci];
-                bs->packed[accepted] = cand;
-                bs->maxp[accepted] = 0;
-                best[k0 + accepted] = cand;
+                acc_ci[accepted] = (uint16_t)ci;
                 if (tt && n_tt == 0) { bs->tt_index = accepted; bs->tt_token = a; }
             }
             if (tt) { tt_slots[slot >> 6] |= 1ull << (slot & 63u); ++n_tt; }
             ++accepted;
             if (single) { cut = 3u; ++ci; break; }
+        }
+        // the members' records, all lanes at once
+        for (uint32_t i = tid; i < accepted; i += kWave) {
+            const uint32_t at = acc_ci[i];
+            const unsigned long long cand = sp[at];
+            bs->key[i] = ~(uint32_t)cand;
+            bs->eidx[i] = si[at];
+            bs->packed[i] = cand;
+            bs->maxp[i] = 0;
+            best[k0 + i] = cand;
         }
         // (candidates passed over behind the last member do not matter: nothing was chosen after them)
         if (tid == 0) {
