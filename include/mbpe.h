@@ -96,6 +96,11 @@ typedef struct {
     uint32_t size_hist[8];     /* passes by merges committed: 1, 2-3, 4-7, 8-15, 16-31, 32-63, 64-127, 128 and more */
     uint32_t n_skipped;        /* dependent candidates passed over by the selection (merged in a later pass) */
     uint32_t n_skip_cut;       /* ... that had not fallen behind the batch after all (the batch was cut there) */
+    uint64_t exchange_words;   /* multi-GPU: u32 words sum-all-reduced for the count deltas of all sequences so far */
+    uint32_t exchanges;        /* ... in this many all-reduces (one per sequence) */
+    uint32_t n_log_passes;     /* fused passes whose count deltas went through the record log (no scattered atomics) */
+    uint64_t log_records;      /* records those passes logged (two per match, padding included) */
+    uint64_t log_spilled;      /* records that found the log full and were added with atomics instead */
 } mbpe_stats;
 
 MBPE_API const char *mbpe_last_error(void);

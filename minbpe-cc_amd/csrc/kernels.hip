@@ -88,11 +88,13 @@ __device__ __forceinline__ uint32_t wave_sum_le8(uint32_t v, unsigned long long 
 
 // ---- pair table device ops ------------------------------------------------
 
-// Count-delta vectors of up to kBatchMax simultaneous merges, x-major so that
-// the ids that exist (x < 256 + k) form a contiguous prefix:
-//   L_j[x] = LR[lr_idx(x, j, 0)],  R_j[y] = LR[lr_idx(y, j, 1)]
-__device__ __forceinline__ uint32_t lr_idx(uint32_t x, uint32_t j, uint32_t side) {
-    return ((x * kBatchMax + j) << 1) | side;
+// Count-delta vectors of up to kBatchMax simultaneous merges, pair-major: member j owns the two rows 2j (L_j) and
+// 2j + 1 (R_j) of `pitch` cells each, pitch = lr_pitch(ids that exist when the sequence starts), so that the cells a
+// batch of n pairs can touch are the prefix [0, 2 * n * pitch) of the block -- what a multi-GPU run exchanges:
+//   L_j[x] = LR[lr_idx(pitch, x, j, 0)],  R_j[y] = LR[lr_idx(pitch, y, j, 1)]
+// (largest index: 2048 rows of 65,536 cells = 2^27)
+__device__ __forceinline__ uint32_t lr_idx(uint32_t pitch, uint32_t x, uint32_t j, uint32_t side) {
+    return (2u * j + side) * pitch + x;
 }
 
 // Count deltas of frequent neighbours.  In text a pair such as ("e", " ") has millions of
@@ -1304,6 +1306,7 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
                                              uint32_t X, uint32_t *LR, DeltaCache &dc, bool dc_on,
                                              const uint32_t *run_in,
                                              uint32_t &wave_m, uint32_t &wave_adj, uint32_t &wave_rm) {
+    const uint32_t pitch = lr_pitch(X);
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     const uint32_t lane = lane_id();
@@ -1408,14 +1411,14 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
             ++my_m;
             if (left_open<MODE>(p1)) {
                 if (prev_adjacent) ++my_adj;
-                else dc_add(dc, dc_on, LR, lr_idx(p1, 0, 0), 1u);
+                else dc_add(dc, dc_on, LR, lr_idx(pitch, p1, 0, 0), 1u);
             }
         } else if (bmatch) {
             nv = kHole;
             ++my_rm;
             if (right_open<MODE>(self, n1)) {
                 const bool next_adjacent = (n1 == a) && ((n2 & idmask) == b);
-                if (!next_adjacent) dc_add(dc, dc_on, LR, lr_idx(n1 & idmask, 0, 1), 1u);
+                if (!next_adjacent) dc_add(dc, dc_on, LR, lr_idx(pitch, n1 & idmask, 0, 1), 1u);
             }
         }
         p2 = p1; p1 = self;       // neighbours are the OLD tokens
@@ -1593,9 +1596,9 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
         const uint32_t key = ~(uint32_t)best;
         const uint32_t a = key >> 16, b = key & 0xFFFFu;
         patch_sums(sums, side, chg, n_chg_words, x, gridDim.x * blockDim.x);
+        const uint32_t pitch = lr_pitch(X);
         for (uint32_t xx = x; xx < X; xx += gridDim.x * blockDim.x) {
-            uint2 *cell = reinterpret_cast<uint2 *>(LR + lr_idx(xx, 0, 0));
-            const uint2 lr = *cell;
+            const uint2 lr = make_uint2(LR[lr_idx(pitch, xx, 0, 0)], LR[lr_idx(pitch, xx, 0, 1)]);
             if (lr.x) {
                 table_add(t, ctl, (xx << 16) | a, -(int32_t)lr.x, false);
                 table_add(t, ctl, (xx << 16) | X, (int32_t)lr.x, true);
@@ -1604,7 +1607,8 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
                 table_add(t, ctl, (b << 16) | xx, -(int32_t)lr.y, false);
                 table_add(t, ctl, (X << 16) | xx, (int32_t)lr.y, true);
             }
-            if (lr.x | lr.y) *cell = make_uint2(0, 0);
+            if (lr.x) LR[lr_idx(pitch, xx, 0, 0)] = 0;
+            if (lr.y) LR[lr_idx(pitch, xx, 0, 1)] = 0;
         }
         if (x == 0) {
             const uint32_t m = gm_gadj ? gm_gadj[0] : ctl->m;
@@ -2500,7 +2504,8 @@ __device__ __forceinline__ Neigh tile_neighbours(const uint32_t s[8], const Halo
 template <int MODE, int DIAG = 0>
 __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, const uint32_t s[8], const Halo h,
                                                const BatchLut &lut, uint32_t n_keys, uint32_t *hdr_adj,
-                                               uint32_t *LR, DeltaCache &dc, bool dc_on, bool tt_on, TTInfo &ti) {
+                                               uint32_t *LR, uint32_t pitch, DeltaCache &dc, bool dc_on, bool tt_on,
+                                               TTInfo &ti) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     const Neigh nb = tile_neighbours(s, h);
@@ -2526,7 +2531,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
             any = true;
             if (right_open<MODE>(self, n1) && !pair_test(lut, n1, n2 & idmask)) {
                 const int jb = lut_index(lut, p1, self & idmask);
-                if (DIAG != 3) dc_add(dc, dc_on, LR, lr_idx(n1 & idmask, (uint32_t)jb, 1), 1u);
+                if (DIAG != 3) dc_add(dc, dc_on, LR, lr_idx(pitch, n1 & idmask, (uint32_t)jb, 1), 1u);
                 else asm volatile("" :: "v"(jb));
             }
         } else if (n1 != kHole && pair_test(lut, self, n1 & idmask)) {   // first token of a match
@@ -2540,7 +2545,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
                     const int jp = lut_index(lut, p2, p1);
                     atomicAdd(&hdr_adj[jp * kBatchMax + ja], 1u);
                 } else {
-                    if (DIAG != 3) dc_add(dc, dc_on, LR, lr_idx(p1, (uint32_t)ja, 0), 1u);
+                    if (DIAG != 3) dc_add(dc, dc_on, LR, lr_idx(pitch, p1, (uint32_t)ja, 0), 1u);
                     else asm volatile("" :: "v"(ja));
                 }
             }
@@ -2570,6 +2575,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     if ((bs->tt_index != kNoTT) != TT) return;      // (see k_fused_batch)
     __shared__ TTInfo ti;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
+    const uint32_t pitch = rfl(lr_pitch(256u + ctl->k_done));
     if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
@@ -2629,7 +2635,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             bool work = __ballot(cand) != 0ull || pair_test(lut, h.p1, tile_first & idmask);
             if (DIAG == 2) { asm volatile("" :: "v"((uint32_t)cand)); work = false; }
-            if (work) scan_tile_full<MODE, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, dc, dc_on, TT, ti);
+            if (work) scan_tile_full<MODE, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, pitch, dc, dc_on, TT, ti);
         }
         if (!v1) break;
         tile += n_waves;
@@ -2671,6 +2677,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
                                                  DeltaCache &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
+    const uint32_t pitch = lr_pitch(X0);        // uniform
     // (an opaque copy of the lane id: the 64-bit lane masks below are cheaper to rebuild per tile than
     //  to keep in registers across the streaming loop, where the compiler would spill them)
     uint32_t lane = lane_id();
@@ -2747,9 +2754,9 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
             if (counted && DIAG != 2) {
                 if (is_a && ((touch >> j) & 1u)) {        // ... (a', b') (a, b): (b', a) -> (X', X)
                     atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
-                    dc_add(dc, dc_on, LR, lr_idx(self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b')
+                    dc_add(dc, dc_on, LR, lr_idx(pitch, self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b')
                 } else {
-                    dc_add(dc, dc_on, LR, lr_idx(nb & idmask, ja, is_a ? 0u : 1u), 1u);
+                    dc_add(dc, dc_on, LR, lr_idx(pitch, nb & idmask, ja, is_a ? 0u : 1u), 1u);
                 }
             }
             pjb = is_a ? pjb : pj;
@@ -2943,31 +2950,34 @@ __global__ __launch_bounds__(kWave) void k_adj_sums(const uint32_t *__restrict__
 }
 
 // per pair j: the largest packed value among the pairs (x, X_j), (X_j, y) it creates
-__global__ void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, const DevCtl *ctl) {
+// (work item = kLrChunk cells of one row of the LR block; a workgroup takes items with a grid stride)
+constexpr uint32_t kLrChunk = 4096;
+__global__ __launch_bounds__(256) void k_delta_max(const uint32_t *__restrict__ LR, BatchState *bs, const DevCtl *ctl) {
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2) return;
     const uint32_t X = 256u + ctl->k_done;
-    const uint64_t total = (uint64_t)X * kBatchMax;
-    // the stride is a multiple of kBatchMax, so a thread only ever sees one pair index j
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t j = (uint32_t)(gid % kBatchMax);
-    if (j >= n_keys) return;
-    const uint32_t in = bs->adj_in[j], out = bs->adj_out[j], Xj = X + j;
-    unsigned long long mp = 0;
-    for (uint64_t i = gid; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint2 lr = reinterpret_cast<const uint2 *>(LR)[i];
-        const uint32_t x = (uint32_t)(i / kBatchMax);
-        if (lr.x) {
-            const unsigned long long p = pack_best((int32_t)(lr.x + in), (x << 16) | Xj);
-            mp = p > mp ? p : mp;
+    const uint32_t pitch = lr_pitch(X);
+    const uint32_t chunks = (X + kLrChunk - 1u) / kLrChunk;          // per row
+    const uint32_t n_items = 2u * n_keys * chunks;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint32_t row = item / chunks, x0 = (item - row * chunks) * kLrChunk;
+        const uint32_t j = row >> 1, side = row & 1u, Xj = X + j;
+        const uint32_t add = side ? bs->adj_out[j] : bs->adj_in[j];
+        const uint32_t *cells = LR + (size_t)row * pitch;
+        unsigned long long mp = 0;
+#pragma unroll 4
+        for (uint32_t x = x0 + threadIdx.x; x < x0 + kLrChunk && x < X; x += 256u) {
+            const uint32_t v = cells[x];
+            if (v) {
+                const unsigned long long p = pack_best((int32_t)(v + add), side ? (Xj << 16) | x : (x << 16) | Xj);
+                mp = p > mp ? p : mp;
+            }
         }
-        if (lr.y) {
-            const unsigned long long p = pack_best((int32_t)(lr.y + out), (Xj << 16) | x);
-            mp = p > mp ? p : mp;
-        }
+        mp = wave_max_u64(mp);
+        // (maxp only grows: most waves see that another one already put a larger value there)
+        if (lane_id() == 0 && mp > __hip_atomic_load(&bs->maxp[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&bs->maxp[j], mp);
     }
-    // (maxp only grows: most threads see that another one already put a larger value there)
-    if (mp > __hip_atomic_load(&bs->maxp[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bs->maxp[j], mp);
 }
 
 // How many pairs of the batch the sequential algorithm would really have chosen in this order
@@ -3008,6 +3018,7 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
     if (n < 2) return;
     if (tid == 0) s_minfrac = 0xFFFFFFFFu;
     const uint32_t X0 = 256u + ctl->k_done;
+    const uint32_t pitch = lr_pitch(X0);
     s_run[tid] = tid < n ? bs->maxp[tid] : 0ull;
     if (tid == 0) s_commit = n;
     __syncthreads();
@@ -3037,8 +3048,8 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
             uint32_t n_dep = 0;
             for (uint32_t i = lane; i < pos && i < n; i += kWave) {
                 const uint32_t ai = bs->key[i] >> 16, bi = bs->key[i] & 0xFFFFu;
-                if (d == ai) { red += LR[lr_idx(c, i, 0)]; ++n_dep; }
-                if (c == bi) { red += LR[lr_idx(d, i, 1)]; ++n_dep; }
+                if (d == ai) { red += LR[lr_idx(pitch, c, i, 0)]; ++n_dep; }
+                if (c == bi) { red += LR[lr_idx(pitch, d, i, 1)]; ++n_dep; }
             }
 #pragma unroll
             for (int dd = kWave / 2; dd > 0; dd >>= 1) {
@@ -3077,10 +3088,10 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
         const uint32_t w = hdr_adj[i];
         if (!w) continue;
         if (r >= commit && q < commit) {            // dropped match r directly before kept match q
-            atomicAdd(&LR[lr_idx(bs->key[r] & 0xFFFFu, q, 0)], w);
+            atomicAdd(&LR[lr_idx(pitch, bs->key[r] & 0xFFFFu, q, 0)], w);
             hdr_adj[i] = 0;
         } else if (r < commit && q >= commit) {     // kept match r directly before dropped match q
-            atomicAdd(&LR[lr_idx(bs->key[q] >> 16, r, 1)], w);
+            atomicAdd(&LR[lr_idx(pitch, bs->key[q] >> 16, r, 1)], w);
             hdr_adj[i] = 0;
         }
     }
@@ -3106,31 +3117,37 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
     const uint32_t commit = ctl->commit_n;
     const uint32_t k0 = ctl->k_done;
     const uint32_t X0 = 256u + k0;
-    const uint64_t total = (uint64_t)X0 * kBatchMax;
+    const uint32_t pitch = lr_pitch(X0);
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint64_t i = gid; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t j = (uint32_t)(i % kBatchMax), x = (uint32_t)(i / kBatchMax);
-        if (j >= n) continue;
-        uint2 *cell = reinterpret_cast<uint2 *>(LR) + i;
-        const uint2 lr = *cell;
-        if (!(lr.x | lr.y)) continue;
-        *cell = make_uint2(0, 0);
-        if (j >= commit) continue;
-        const uint32_t a = bs->key[j] >> 16, b = bs->key[j] & 0xFFFFu, X = X0 + j;
-        if (lr.x) {
-            table_add(t, ctl, (x << 16) | a, -(int32_t)lr.x, false);
-            table_add(t, ctl, (x << 16) | X, (int32_t)lr.x, true);
-        }
-        if (lr.y) {
-            table_add(t, ctl, (b << 16) | x, -(int32_t)lr.y, false);
-            table_add(t, ctl, (X << 16) | x, (int32_t)lr.y, true);
+    {   // (work item = kLrChunk cells of one row of the LR block, as in k_delta_max)
+        const uint32_t chunks = (X0 + kLrChunk - 1u) / kLrChunk;
+        const uint32_t n_items = 2u * n * chunks;
+        for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+            const uint32_t row = item / chunks, x0 = (item - row * chunks) * kLrChunk;
+            const uint32_t j = row >> 1, side = row & 1u, X = X0 + j;
+            const uint32_t a = bs->key[j] >> 16, b = bs->key[j] & 0xFFFFu;
+            uint32_t *cells = LR + (size_t)row * pitch;
+            for (uint32_t x = x0 + threadIdx.x; x < x0 + kLrChunk && x < X0; x += blockDim.x) {
+                const uint32_t v = cells[x];
+                if (!v) continue;
+                cells[x] = 0;
+                if (j >= commit) continue;
+                if (!side) {
+                    table_add(t, ctl, (x << 16) | a, -(int32_t)v, false);
+                    table_add(t, ctl, (x << 16) | X, (int32_t)v, true);
+                } else {
+                    table_add(t, ctl, (b << 16) | x, -(int32_t)v, false);
+                    table_add(t, ctl, (X << 16) | x, (int32_t)v, true);
+                }
+            }
         }
     }
-    if (gid < (uint64_t)kBatchMax * kBatchMax) {
-        const uint32_t p = (uint32_t)gid / kBatchMax, j = (uint32_t)gid % kBatchMax;
-        const uint32_t adj = hdr_adj[gid];
+    // (the rows p < n of the ADJ block, whatever the grid)
+    for (uint64_t g = gid; g < (uint64_t)n * kBatchMax; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = (uint32_t)(g / kBatchMax), j = (uint32_t)(g % kBatchMax);
+        const uint32_t adj = hdr_adj[g];
         if (adj) {
-            hdr_adj[gid] = 0;
+            hdr_adj[g] = 0;
             if (p < commit && j < commit) {     // match of p directly followed by a match of j
                 const uint32_t bp = bs->key[p] & 0xFFFFu, aj = bs->key[j] >> 16;
                 table_add(t, ctl, (bp << 16) | aj, -(int32_t)adj, false);
@@ -3194,17 +3211,19 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
     const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
     if (x0 < X0 && j0 < n) {
         if (threadIdx.x < (uint32_t)kApplyTile) keys[threadIdx.x] = j0 + threadIdx.x < n ? bs->key[j0 + threadIdx.x] : 0u;
-        // load (and clear) the deltas of ids x0.. and pairs j0..: rows along j are contiguous in LR
-        for (uint32_t r = wave; r < (uint32_t)kApplyTile; r += 256 / kWave) {
-            const uint32_t x = x0 + r, j = j0 + lane;
+        // load (and clear) the deltas of ids x0.. and pairs j0..: the rows L_j, R_j of LR are contiguous along x
+        const uint32_t pitch = lr_pitch(X0);
+        for (uint32_t c = wave; c < (uint32_t)kApplyTile; c += 256 / kWave) {
+            const uint32_t x = x0 + lane, j = j0 + c;
             uint2 lr = make_uint2(0, 0);
             if (x < X0 && j < n) {
-                uint2 *cell = reinterpret_cast<uint2 *>(LR) + ((uint64_t)x * kBatchMax + j);
-                lr = *cell;
-                if (lr.x | lr.y) *cell = make_uint2(0, 0);
+                uint32_t *cl = LR + (size_t)(2u * j) * pitch + x, *cr = cl + pitch;
+                lr = make_uint2(*cl, *cr);
+                if (lr.x) *cl = 0;
+                if (lr.y) *cr = 0;
                 if (j >= commit) lr = make_uint2(0, 0);
             }
-            tile[r][lane] = lr;
+            tile[lane][c] = lr;
         }
         __syncthreads();
         // The decrements return the old value (an absent pair or a negative count is an error worth
@@ -3979,10 +3998,10 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     const uint64_t cells = (uint64_t)id_upper * kBatchMax;
     uint32_t blocks = (uint32_t)((cells + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    if (blocks < 2) blocks = 2;
+    if (blocks < 8) blocks = 8;            // (k_apply_batch: at least kBatchMax threads, for the per-pair part)
     hipLaunchKernelGGL(k_adj_sums, dim3(kBatchMax), dim3(kWave), 0, s, hdr_adj, bs, ctl);
-    // (the grid's thread count stays a multiple of kBatchMax: see the kernel)
-    hipLaunchKernelGGL(k_delta_max, dim3(blocks < 1024 ? (blocks + 3u) / 4u * 4u : 1024), dim3(256), 0, s, LR, bs, ctl);
+    // (work items of k_delta_max: 4096 cells of one LR row each)
+    hipLaunchKernelGGL(k_delta_max, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, LR, bs, ctl);
     hipLaunchKernelGGL(k_adj_max, dim3(kBatchMax / 4), dim3(256), 0, s, hdr_adj, bs, ctl);
     hipLaunchKernelGGL(k_validate, dim3(1), dim3(kValThreads), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     if (t.cells) {

@@ -191,8 +191,14 @@ struct BatchState {
 };
 
 // exchange buffer (u32 words): [single-merge header: m, adj, RankEdge x n_ranks]
-//   [batch header: m_j (kBatchMax), ADJ[i][j] (kBatchMax^2)] [LR_j blocks: 2*stride words each]
+//   [batch header: m_j (kBatchMax), ADJ[i][j] (kBatchMax^2)] [LR: rows L_0, R_0, L_1, R_1, ... of lr_pitch(ids) cells]
 inline uint32_t batch_header_words() { return (uint32_t)(kBatchMax + kBatchMax * kBatchMax); }
+// row pitch of the LR block for a sequence that starts with `ids` token ids (256 + merges done): the ids rounded up
+// to 64 cells, so that rows start on 256-byte lines.  A batch of n pairs touches the first 2 * n * pitch cells.
+__host__ __device__ inline uint32_t lr_pitch(uint32_t ids) { return (ids + 63u) & ~63u; }
+__host__ __device__ inline unsigned long long lr_words(uint32_t ids, uint32_t n_pairs) {
+    return 2ull * (n_pairs ? n_pairs : 1u) * lr_pitch(ids);
+}
 
 constexpr uint32_t kErrTableFull   = 1u;
 constexpr uint32_t kErrNegCount    = 2u;

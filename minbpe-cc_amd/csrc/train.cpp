@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -210,6 +211,10 @@ struct mbpe_ctx {
                                     //   (no faster on text: words make chains of pairs with one count)
     int64_t opt_first = 0;          // 1: `first` tie-break (insertion order, PairCount.h:65-74) instead of lexical
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
+    // multi-GPU: what the selection of the sequence in flight decided (k_done, k_limit, batch_n, commit_n of DevCtl),
+    // read back while its stream pass runs, so that exactly the cells the batch can touch are exchanged
+    uint32_t *h_seq = nullptr;      // pinned, 4 words
+    hipEvent_t ev_sel = nullptr;
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
     std::vector<hipEvent_t> kev_f;  // ... around the fused pass alone
     uint32_t *seq_flags = nullptr;  // per sequence of a group: 1 = a fused pass ran (opt_time_kernels)
@@ -451,7 +456,9 @@ int mbpe_create(int device_id, mbpe_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_seq), 64, hipHostMallocDefault) != hipSuccess) {
         mbpe_host::set_last_error("could not create HIP stream / events");
         delete c;
         return MBPE_ERR_HIP;
@@ -474,6 +481,8 @@ void mbpe_destroy(mbpe_ctx *c) {
     for (hipEvent_t e : c->kev_f) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
+    if (c->h_seq) (void)hipHostFree(c->h_seq);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -713,7 +722,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(tmalloc(c, &c->tile_list, ((size_t)c->n_tiles + 64) * 4));
     HIPCHK(hipMemsetAsync(c->chg, 0, ((size_t)c->n_tiles / 32 + 2) * 4, c->stream));
     HIPCHK(tmalloc(c, &c->offsets, ((size_t)c->n_tiles + tile_scan_scratch(c->n_tiles)) * 8));
-    const size_t xb_words = (size_t)c->hdr_words + c->hdrb_words + 2 * (size_t)kBatchMax * vocab_size + 8;
+    const size_t xb_words = (size_t)c->hdr_words + c->hdrb_words + lr_words(vocab_size, kBatchMax) + 8;
     const size_t xb0_words = 65536 + (size_t)c->hdr_words;
     HIPCHK(tmalloc(c, &c->xb, xb_words * 4));
     HIPCHK(tmalloc(c, &c->xb0, xb0_words * 4));
@@ -850,11 +859,27 @@ static void step_finish(mbpe_ctx *c) {
     c->k++;
 }
 
-// words of xb a merge has to exchange: both headers + the LR cells of the ids that exist (x < X)
-static size_t exchange_words(const mbpe_ctx *c, uint32_t id_upper) {
-    return (size_t)c->hdr_words + c->hdrb_words + 2 * (size_t)kBatchMax * id_upper;
+// words of xb a sequence has to exchange: both headers + the LR rows of its n_pairs members, lr_pitch(ids) cells each
+// (ids = 256 + merges done when the sequence started: the neighbours x that can occur)
+static size_t exchange_words(const mbpe_ctx *c, uint32_t ids, uint32_t n_pairs) {
+    return (size_t)c->hdr_words + c->hdrb_words + (size_t)lr_words(ids, n_pairs);
 }
-static size_t step_exchange_words(const mbpe_ctx *c) { return exchange_words(c, 256 + c->k); }
+static size_t step_exchange_words(const mbpe_ctx *c) { return exchange_words(c, 256 + c->k, 1); }
+
+// k_done / batch_n of the sequence whose selection has been enqueued: copied to pinned memory behind it
+static_assert(offsetof(DevCtl, batch_n) == offsetof(DevCtl, k_done) + 8 && offsetof(DevCtl, commit_n) == offsetof(DevCtl, k_done) + 12,
+              "seq_info_enqueue copies k_done, k_limit, batch_n, commit_n as four consecutive words");
+static int seq_info_enqueue(mbpe_ctx *c) {
+    HIPCHK(hipMemcpyAsync(c->h_seq, &c->ctl->k_done, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->ev_sel, c->stream));
+    return MBPE_OK;
+}
+static int seq_info_wait(mbpe_ctx *c, uint32_t *ids, uint32_t *n_pairs) {
+    HIPCHK(hipEventSynchronize(c->ev_sel));
+    *ids = 256u + c->h_seq[0];
+    *n_pairs = c->h_seq[2];
+    return MBPE_OK;
+}
 
 // ---- batch sequences: select -> (single pair: fused merge | several pairs: scan, validate, rewrite) ----
 // The merge counter lives on the device (ctl->k_done); the host only keeps an
@@ -876,6 +901,7 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     if (c->opt_first)
         launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best, c->first_state, c->tok[0], c->tok[1], c->sums, c->n_tiles,
                               endbit, c->n_cus, 1);
+    if (multi) (void)seq_info_enqueue(c);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     // (the live token buffer is ctl->cur: a fused pass flips it without the host knowing)
     launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
@@ -1012,8 +1038,14 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
              ++g, ++launched) {
             seq_stage_a(c, c->opt_time_kernels ? (int)g : -1);
             if (is_multi(c)) {
-                int rc = comm_allreduce(c, c->xb, exchange_words(c, 256 + std::min<uint32_t>(
-                                                      c->n_target, c->k_upper + (uint32_t)c->opt_max_batch)));
+                // (the selection's result arrives while the stream pass runs: every rank took the same decisions, so
+                //  the counts agree, and the all-reduce is enqueued long before the pass ends)
+                uint32_t ids = 0, n_pairs = 0;
+                int rc = seq_info_wait(c, &ids, &n_pairs);
+                if (rc != MBPE_OK) return rc;
+                c->stats.exchange_words += exchange_words(c, ids, n_pairs);
+                c->stats.exchanges++;
+                rc = comm_allreduce(c, c->xb, exchange_words(c, ids, n_pairs));
                 if (rc != MBPE_OK) return rc;
             }
             c->seq_slot = c->opt_time_kernels ? (int)g : -1;
@@ -1196,7 +1228,12 @@ int mbpe_comm_exchange_buffer(mbpe_ctx *c, void **dev_ptr_out, uint64_t *n_u32_o
     case 2: *dev_ptr_out = c->xb; *n_u32_out = step_exchange_words(c); return MBPE_OK;
     case 3:     // deltas of a batch sequence
         *dev_ptr_out = c->xb;
-        *n_u32_out = exchange_words(c, 256 + std::min<uint32_t>(c->n_target, c->k + (uint32_t)c->opt_max_batch));
+        {
+            uint32_t ids = 0, n_pairs = 0;
+            int rc = seq_info_wait(c, &ids, &n_pairs);
+            if (rc != MBPE_OK) return rc;
+            *n_u32_out = exchange_words(c, ids, n_pairs);
+        }
         return MBPE_OK;
     case 4: *dev_ptr_out = c->xb; *n_u32_out = c->hdr_words; return MBPE_OK;   // rank edges
     default: break;
