@@ -252,6 +252,12 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *                   (default), 0 = always walk the argmax bounds pair by pair
  *   "sel_cap"       capacity of the candidate list of the threshold selection (default and
  *                   limit 4096, at least 64; tests lower it to force the overflow path)
+ *   "delta_log"     1 (default) = a fused pass with at least 2^18 matches logs its count deltas (two
+ *                   per match) as records that are partitioned and counted in LDS afterwards; 2 =
+ *                   every fused pass does; 0 = none: they are added to the delta block with global
+ *                   atomics.  Same results.  Read by the next mbpe_train_begin.
+ *   "delta_log_cap" capacity of that log in records (0, the default: by the size of the stream);
+ *                   records that find it full are added with atomics (tests set it small)
  *   "hier_argmax"   -1 auto / 0 scan every entry / 1 walk the block bounds
  *                   (single-merge mode)
  *   "force_exchange" 1 = take the multi-rank path (rank edges, exchange) even
