@@ -129,12 +129,26 @@ def cpu_baseline(data, merges, what):
     }
 
 
-COPY_ONLY_GBS = 5100.0        # k_fused_batch with everything but the tile copy compiled out (MBPE_FUSED_DIAG=4): 17.2 GB in 3.37 ms
-ATOMIC_UNIT_GPS = 24.4        # scattered global atomicAdd, 2 active lanes per instruction, any table size up to 256 MB
-FUSED_LIMITER = ("per-match work on top of the pass's copy floor (3.4 ms for 17.2 GB = 0.64 of peak): two scattered global "
-                 "atomics per match (the atomic unit does 24 G/s whatever the table size, tools/atomic_footprint.hip) and "
-                 "vector-instruction issue; a pass of up to 1024 merges holds ~5e7 matches: see floor_model (DESIGN.md section 4, "
-                 "profiles/r02_fused_ablation.md)")
+# What a fused pass cannot go below, from measurements kept under profiles/ (profiles/make_floor_json.py writes the
+# file from a timing-only build of the kernel and from the SQ counters of the shipped one; nothing is hard-coded here):
+#   copy_only_GBps   k_fused_batch with everything but the tile copy compiled out (MBPE_FUSED_DIAG=4)
+#   valu_per_tile    vector instructions the shipped kernel executes per 512-slot tile (SQ_INSTS_VALU / tiles)
+#   clock_GHz        shader clock during the pass (SQ_BUSY_CYCLES per shader engine / duration)
+FLOOR_FILE = os.path.join("profiles", "r03_fused_floor.json")
+FUSED_LIMITER = ("vector-instruction issue: ~490 vector instructions per 512-slot tile (8 lookup-table tests, next / "
+                 "previous-live-token chains over the holes, carry chains for second tokens and touching matches, tile "
+                 "summaries, ~190 for a dozen matches) keep the SIMDs ~80 % busy at 4 waves per SIMD; the two count-delta "
+                 "atomics per match execute at the memory side meanwhile -- taking them out of the kernel (record log) or "
+                 "processing the matches densely changed neither the instruction count nor the time "
+                 "(profiles/r03_fused_log_ab.md, DESIGN.md section 4)")
+
+
+def fused_floor():
+    try:
+        with open(os.path.join(ROOT, FLOOR_FILE)) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def main():
@@ -253,20 +267,21 @@ def main():
         pass_bytes = 2.0 * s1["n_slots"]
         limiter = None
     achieved = pass_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # what a fused pass cannot go below: its bytes at the rate of the copy-only build of the same kernel, plus two
-    # scattered global atomics per match at the rate of the unit that executes them (they do not overlap)
+    # what a fused pass cannot go below: its bytes at the rate of the copy-only build of the same kernel, and its vector
+    # instructions at one per 4 cycles and SIMD (wave64 on a SIMD that retires 16 lanes per cycle); the larger one binds
     floor_model = None
     if roof_name == "k_fused_batch":
-        matches = (s0["n_live"] - s1["n_live"]) / max(n_pass, 1)            # a match removes one token (this rank's shard)
-        stream_ms = pass_bytes / (COPY_ONLY_GBS * 1e9) * 1e3
-        atomics_ms = 2.0 * matches / (ATOMIC_UNIT_GPS * 1e9) * 1e3
-        floor_model = {"stream_ms": stream_ms, "copy_only_GBps": COPY_ONLY_GBS,
-                       "matches_per_launch": matches, "atomics_per_launch": 2.0 * matches,
-                       "atomic_unit_G_per_s": ATOMIC_UNIT_GPS, "atomics_ms": atomics_ms,
-                       "sum_ms": stream_ms + atomics_ms, "measured_ms": avg_ms,
-                       "sources": "copy-only build of the kernel: profiles/r02_fused_ablation.md; atomic unit: "
-                                  "tools/atomic_footprint.hip (flat from 256 KB to 256 MB); additive: "
-                                  "tools/atomic_overlap.hip"}
+        fl = fused_floor()
+        if fl:
+            tiles = (s1["fused_slots"] - s0["fused_slots"]) / n_fused / 512.0
+            stream_ms = pass_bytes / (fl["copy_only_GBps"] * 1e9) * 1e3
+            valu_ms = fl["valu_per_tile"] * tiles * 4.0 / (fl["simds"] * fl["clock_GHz"] * 1e9) * 1e3
+            floor_model = {"stream_ms": stream_ms, "copy_only_GBps": fl["copy_only_GBps"],
+                           "valu_issue_ms": valu_ms, "valu_per_tile": fl["valu_per_tile"], "tiles_per_launch": tiles,
+                           "clock_GHz": fl["clock_GHz"], "simds": fl["simds"],
+                           "matches_per_launch": (s0["n_live"] - s1["n_live"]) / max(n_pass, 1),
+                           "floor_ms": max(stream_ms, valu_ms), "measured_ms": avg_ms,
+                           "sources": FLOOR_FILE + " (" + fl.get("sources", "") + ")"}
     # SURVEY.md 8(d) prices a merge step at 2 B x L read + 2 B x L' written; a pass performs
     # merges_per_pass of them on one read: the same sum divided by the measured time
     live_avg = 0.5 * (s0["n_live"] + s1["n_live"])

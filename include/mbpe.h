@@ -98,9 +98,7 @@ typedef struct {
     uint32_t n_skip_cut;       /* ... that had not fallen behind the batch after all (the batch was cut there) */
     uint64_t exchange_words;   /* multi-GPU: u32 words sum-all-reduced for the count deltas of all sequences so far */
     uint32_t exchanges;        /* ... in this many all-reduces (one per sequence) */
-    uint32_t n_log_passes;     /* fused passes whose count deltas went through the record log (no scattered atomics) */
-    uint64_t log_records;      /* records those passes logged (two per match, padding included) */
-    uint64_t log_spilled;      /* records that found the log full and were added with atomics instead */
+    uint32_t pad_;
 } mbpe_stats;
 
 MBPE_API const char *mbpe_last_error(void);
@@ -252,12 +250,6 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *                   (default), 0 = always walk the argmax bounds pair by pair
  *   "sel_cap"       capacity of the candidate list of the threshold selection (default and
  *                   limit 4096, at least 64; tests lower it to force the overflow path)
- *   "delta_log"     1 (default) = a fused pass with at least 2^18 matches logs its count deltas (two
- *                   per match) as records that are partitioned and counted in LDS afterwards; 2 =
- *                   every fused pass does; 0 = none: they are added to the delta block with global
- *                   atomics.  Same results.  Read by the next mbpe_train_begin.
- *   "delta_log_cap" capacity of that log in records (0, the default: by the size of the stream);
- *                   records that find it full are added with atomics (tests set it small)
  *   "hier_argmax"   -1 auto / 0 scan every entry / 1 walk the block bounds
  *                   (single-merge mode)
  *   "force_exchange" 1 = take the multi-rank path (rank edges, exchange) even

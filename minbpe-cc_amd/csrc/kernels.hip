@@ -137,6 +137,12 @@ __device__ __forceinline__ void dc_flush(DeltaCache &dc, uint32_t *LR) {
     }
 }
 
+// is the largest pair of the pass frequent enough for hot count cells?  (one occurrence per
+// 8192 live tokens; counts are global, so n_live is this shard's live tokens times the ranks)
+__device__ __forceinline__ bool dc_wanted(unsigned long long top_count, unsigned long long n_live) {
+    return top_count * 8192ull >= n_live;
+}
+
 __device__ __forceinline__ uint32_t hash_key(uint32_t k) {
     k *= 0x9E3779B1u;
     k ^= k >> 15;
@@ -2661,45 +2667,6 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
 // live.  Everything else (pair index, neighbours, deltas) is only done where a
 // match is.
 
-// The end of a tile of the fused pass, from its new slot values: stand-in ids back to their tokens, tokens removed,
-// the tile's new summary (side array), the packed tile.
-template <int MODE>
-__device__ __forceinline__ uint4 fused_tile_finish(uint32_t out[8], bool tt_on, const TTInfo &ti, uint32_t Lm, uint32_t ABm,
-                                                   uint32_t Bm, unsigned long long m_live, uint32_t old_x, uint32_t old_y,
-                                                   uint32_t old_z, uint32_t tile, TileSum *sout, uint32_t &wave_rm,
-                                                   bool &wrote_sum) {
-    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
-    constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
-    if (tt_on) {                        // (every renamed token was the second token of a match; be safe)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (out[j] != kHole && (out[j] & idmask) >= idmask - (uint32_t)kTTMax)
-                out[j] = ti.tok[idmask - 1u - (out[j] & idmask)] | (out[j] & endbit);
-    }
-    const uint32_t removed = rfl(wave_sum(__popc(Bm)));
-    wave_rm += removed;
-    // New summary.  Heads and tails only change when a match touches one of the first two or
-    // last two live tokens; a trailing run of equal tokens (tail_run > 1) is recounted.
-    const uint32_t top = Lm ? 31u - (uint32_t)__builtin_clz(Lm) : 0u;
-    const uint32_t lb1 = Lm & (0u - Lm), r1 = Lm ^ lb1, lb2 = r1 & (0u - r1);
-    const uint32_t hb1 = Lm ? 1u << top : 0u, r2 = Lm ^ hb1, hb2 = r2 ? 1u << (31u - (uint32_t)__builtin_clz(r2)) : 0u;
-    const uint32_t F = (uint32_t)__builtin_ctzll(m_live), Hl = 63u - (uint32_t)__builtin_clzll(m_live);
-    const unsigned long long mF = m_live & (m_live - 1ull), mH = m_live & ~(1ull << Hl);
-    bool edge = rlane(ABm & (lb1 | lb2), F) != 0u || rlane(ABm & (hb1 | hb2), Hl) != 0u;
-    if (rlane(lb2, F) == 0u && mF) edge |= rlane(ABm & lb1, (uint32_t)__builtin_ctzll(mF)) != 0u;
-    if (rlane(hb2, Hl) == 0u && mH) edge |= rlane(ABm & hb1, 63u - (uint32_t)__builtin_clzll(mH)) != 0u;
-    uint4 ns;
-    if (edge || (old_z >> 16) != 1u) {
-        ns = wave_summary(out);
-    } else {
-        ns = make_uint4(old_x, old_y, (old_z & 0xFFFF0000u) | ((old_z & 0xFFFFu) - removed), 0u);
-    }
-    // (no tile mark: a fused pass writes every tile's summary to the side array, see DevCtl::marks_all)
-    if (lane_id() == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
-    wrote_sum = true;
-    return pack8(out);
-}
-
 template <int MODE, int DIAG = 0>
 __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on, TTInfo &ti,
                                                  const uint32_t s[8], const uint32_t cj[8],
@@ -2799,195 +2766,34 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
         out[j] = nv;
     }
 
-    return fused_tile_finish<MODE>(out, tt_on, ti, Lm, ABm, Bm, m_live, old_x, old_y, old_z, tile, sout, wave_rm, wrote_sum);
-}
-
-// The wave's staged records, 64 at a time: into its chunk of the log (whole 256-byte stores), or -- no log, or the
-// log is full -- added to LR with atomics after all.  What is left (< 64 records) moves to the front of the staging
-// area.  Everything here is wave-uniform control flow; the LDS is in order within a wave, so no barrier is needed.
-struct WaveLog {
-    uint32_t cur;          // records staged
-    uint32_t pos, left;    // the wave's chunk of the log: next record, records left
-    uint32_t logging;      // 1: records go to the log; 0: to LR with atomics
-    uint32_t spilled;      // records that went to LR because the log was full (statistics)
-};
-
-__device__ __forceinline__ void log_flush(WaveLog &wl, uint32_t *stage_w, uint32_t *dlog, LogState *ls, uint32_t *LR,
-                                          uint32_t min_keep) {
-    const uint32_t lane = lane_id();
-    uint32_t done = 0;
-    while (wl.cur - done > min_keep) {                    // (min_keep = 63: whole blocks of 64 only; 0: a padded last one)
-        const uint32_t n = wl.cur - done;
-        uint32_t rec = stage_w[done + lane];
-        if (lane >= n) rec = kLogNull;                    // (only in the padded last block)
-        if (wl.logging && wl.left == 0) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ls->n_alloc, kLogChunk);
-            base = rfl(base);
-            const uint32_t cap = ls->cap;
-            if (cap < kLogChunk || base > cap - kLogChunk) { wl.logging = 0; wl.spilled = 1; }   // full: atomics from here on
-            else { wl.pos = base; wl.left = kLogChunk; }
-        }
-        if (wl.logging) {
-            dlog[wl.pos + lane] = rec;
-            wl.pos += kWave;
-            wl.left -= kWave;
-        } else {
-            if (rec != kLogNull) atomicAdd(&LR[rec & ~kLogNeg], (rec & kLogNeg) ? 0xFFFFFFFFu : 1u);
-            if (wl.spilled) wl.spilled += (uint32_t)__popcll(__ballot(rec != kLogNull));
-        }
-        done += n < (uint32_t)kWave ? n : (uint32_t)kWave;
-    }
-    const uint32_t rem = wl.cur - done;
-    if (done && rem) {
-        const uint32_t v = lane < rem ? stage_w[done + lane] : 0u;    // (rem < 64: one read, then one write, in this order)
-        if (lane < rem) stage_w[lane] = v;
-    }
-    wl.cur = rem;
-}
-
-// ---- the same tile, matches processed densely -------------------------------------------------------
-// fused_tile_full spends its time in eight guarded regions per tile that run ~50 instructions each with one or
-// two of 64 lanes active (a 512-slot tile of the benchmark corpus holds a dozen matches): the fused pass is
-// bound by vector-instruction issue, not by memory.  Here the lanes that OWN the slots only
-// describe their match positions -- first or second token of a match: (token, next live token, previous live
-// token, slot, role), eight bytes, written to LDS in stream order (a sparse wave prefix sum gives every lane its
-// place) -- and then the wave turns around: lane t takes position t, so the pair index lookup, the new token, the
-// neighbour pair that loses an occurrence and its delta record are computed once for up to 64 positions at a time.
-//   * the second token of a match looks its pair up as (previous live token, itself): no index has to travel;
-//   * a match that directly follows another one takes that one's index from the lane before it (stream order);
-//   * the merged tile is patched in an LDS image of the tile (16-bit stores) that the owners read back;
-//   * the delta records (delta_log.hip) are appended by all lanes of the wave at once.
-// Tiles with more than kDenseMax positions (text, frequent pairs) take fused_tile_full.
-constexpr uint32_t kDenseMax = 128;
-struct DenseMem {                            // per wave, in LDS
-    uint2 d[kDenseMax];                      // x: token | next live token << 16;  y: previous live token | flags << 16
-    uint4 img[kWave];                        // the tile being rewritten
-    uint32_t stage[kWave + kDenseMax];       // delta records waiting for a flush
-};
-constexpr uint32_t kDfA = 1u << 9, kDfTouch = 1u << 10;      // flags: bits 0..8 = slot in the tile
-typedef uint16_t __attribute__((may_alias)) u16_alias;
-
-template <int MODE, int DIAG = 0>
-__device__ __forceinline__ uint4 fused_tile_dense(const uint4 q_orig, bool tt_on, TTInfo &ti,
-                                                  const uint32_t s[8], const uint32_t cj[8],
-                                                  uint32_t Am, unsigned long long m_live, uint32_t c_init, const Halo h,
-                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
-                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
-                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
-                                                  DeltaCache &dc, uint32_t &wave_rm, bool &wrote_sum,
-                                                  DenseMem &dm, WaveLog &wl, uint32_t *dlog, LogState *ls) {
-    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
-    constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
-    const uint32_t pitch = lr_pitch(X0);        // uniform
-    uint32_t lane = lane_id();
-    asm volatile("" : "+v"(lane));
-    const unsigned long long lane_bit = 1ull << lane;
-    uint32_t Lm = 0;
+    if (tt_on) {                        // (every renamed token was the second token of a match; be safe)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) Lm |= (s[j] != kHole ? 1u : 0u) << j;
-    const uint32_t Hm = Lm ^ 0xFFu;
-    const unsigned long long E = ~m_live;
-    // (the same carry chains as fused_tile_full: second tokens of matches, matches that touch)
-    const bool lastA = Am > (Lm & ~Am);
-    const unsigned long long G = __ballot(lastA);
-    const bool tcin = pair_test(lut, h.p1, tile_first & idmask);          // uniform
-    const unsigned long long CIN = (((G << 1) | (tcin ? 1ull : 0ull)) + E) & m_live;
-    const uint32_t cin = lane_of(CIN) ? 1u : 0u;
-    const uint32_t Bm = (((Am << 1) | cin) + Hm) & Lm;
-    const bool lastB = Bm > (Lm & ~Bm);
-    const unsigned long long GB = __ballot(lastB);
-    const bool tbin = h.p2 != kHole && pair_test(lut, h.p2, h.p1 & idmask);   // uniform
-    const unsigned long long BIN = (((GB << 1) | (tbin ? 1ull : 0ull)) + E) & m_live;
-    const uint32_t bin = lane_of(BIN) ? 1u : 0u;
-    const uint32_t touch = Am & ((((Bm << 1) | bin) + Hm) & Lm);     // starts a match right after another one
-    const uint32_t ABm = Am | Bm;
-
-    // every lane's place in the list of positions: exclusive prefix sum of the per-lane counts, which are
-    // sparse (mostly 0 or 1): "lanes below me with at least k positions", for k = 1, 2, ... while there are any
-    const uint32_t n_me = (uint32_t)__popc(ABm);
-    uint32_t off = 0, total = 0;
-    for (uint32_t k = 1;; ++k) {
-        const unsigned long long mk = __ballot(n_me >= k);
-        if (mk == 0ull) break;
-        off = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, off));
-        total += (uint32_t)__popcll(mk);
+        for (int j = 0; j < 8; ++j)
+            if (out[j] != kHole && (out[j] & idmask) >= idmask - (uint32_t)kTTMax)
+                out[j] = ti.tok[idmask - 1u - (out[j] & idmask)] | (out[j] & endbit);
     }
-    if (total == 0u) return q_orig;
-    if (total > kDenseMax)
-        return fused_tile_full<MODE, DIAG>(q_orig, tt_on, ti, s, cj, Am, m_live, c_init, h, tile_first, old_x, old_y, old_z, lut,
-                                           X0, tile, sout, chg, hdr_adj, LR, dc, false, wave_rm, wrote_sum);
-
-    // previous live token of every lane's first slot
-    uint32_t ll = kHole;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ll = s[j] != kHole ? s[j] : ll;
-    uint32_t p1;
-    if (m_live == ~0ull) {
-        p1 = wave_from_prev(ll, h.p1);
+    const uint32_t removed = rfl(wave_sum(__popc(Bm)));
+    wave_rm += removed;
+    // New summary.  Heads and tails only change when a match touches one of the first two or
+    // last two live tokens; a trailing run of equal tokens (tail_run > 1) is recounted.
+    const uint32_t top = Lm ? 31u - (uint32_t)__builtin_clz(Lm) : 0u;
+    const uint32_t lb1 = Lm & (0u - Lm), r1 = Lm ^ lb1, lb2 = r1 & (0u - r1);
+    const uint32_t hb1 = Lm ? 1u << top : 0u, r2 = Lm ^ hb1, hb2 = r2 ? 1u << (31u - (uint32_t)__builtin_clz(r2)) : 0u;
+    const uint32_t F = (uint32_t)__builtin_ctzll(m_live), Hl = 63u - (uint32_t)__builtin_clzll(m_live);
+    const unsigned long long mF = m_live & (m_live - 1ull), mH = m_live & ~(1ull << Hl);
+    bool edge = rlane(ABm & (lb1 | lb2), F) != 0u || rlane(ABm & (hb1 | hb2), Hl) != 0u;
+    if (rlane(lb2, F) == 0u && mF) edge |= rlane(ABm & lb1, (uint32_t)__builtin_ctzll(mF)) != 0u;
+    if (rlane(hb2, Hl) == 0u && mH) edge |= rlane(ABm & hb1, 63u - (uint32_t)__builtin_clzll(mH)) != 0u;
+    uint4 ns;
+    if (edge || (old_z >> 16) != 1u) {
+        ns = wave_summary(out);
     } else {
-        const unsigned long long lo = m_live & (lane_bit - 1ull);
-        const uint32_t src = lo ? 63u - (uint32_t)__builtin_clzll(lo) : lane;
-        const uint32_t got = __shfl(ll, src, kWave);
-        p1 = lo ? got : h.p1;
+        ns = make_uint4(old_x, old_y, (old_z & 0xFFFF0000u) | ((old_z & 0xFFFFu) - removed), 0u);
     }
-    // the tile's image, and the descriptors of this lane's positions
-    dm.img[lane] = tt_on ? pack8(s) : q_orig;
-    const uint32_t fl_lane = lane << 3;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t self = s[j];
-        if ((ABm >> j) & 1u) {
-            const uint32_t t = off + (uint32_t)__popc(ABm & ((1u << j) - 1u));
-            const uint32_t fl = (fl_lane | (uint32_t)j) | (((Am >> j) & 1u) ? kDfA : 0u) | (((touch >> j) & 1u) ? kDfTouch : 0u);
-            dm.d[t] = make_uint2(self | (cj[j] << 16), p1 | (fl << 16));
-        }
-        p1 = self != kHole ? self : p1;
-    }
-    asm volatile("" ::: "memory");
-
-    // ---- the wave turns around: lane t takes position t
-    uint32_t edge_idx = tbin ? (uint32_t)lut_index(lut, h.p2, h.p1 & idmask) : 0u;     // uniform: the match that ends the previous tile
-    u16_alias *img16 = reinterpret_cast<u16_alias *>(dm.img);
-    for (uint32_t base = 0; base < total; base += kWave) {
-        const uint32_t t = base + lane;
-        const bool on = t < total;
-        const uint2 d = on ? dm.d[t] : make_uint2(0u, 0u);
-        const uint32_t self = d.x & 0xFFFFu, nx = d.x >> 16, pv = d.y & 0xFFFFu, fl = d.y >> 16;
-        const bool is_a = (fl & kDfA) != 0u, tch = (fl & kDfTouch) != 0u;
-        // the pair this position belongs to: (itself, next) for a first token, (previous, itself) for a second one
-        const uint32_t first = is_a ? self : pv, second = (is_a ? nx : self) & idmask;
-        uint32_t idx = 0;
-        if (on) idx = (uint32_t)lut_index(lut, first, second);
-        const uint32_t prev_idx = wave_from_prev(idx, edge_idx);       // (stream order: the match that ended just before)
-        edge_idx = rlane(idx, kWave - 1);
-        if (on) {
-            img16[fl & 511u] = (u16_alias)(is_a ? (X0 + idx) | (nx & endbit) : kHole);
-            if (tt_on && is_a && second >= idmask - (uint32_t)kTTMax)                  // a match of a (t,t) member: count it
-                atomicAdd(&ti.cnt[idmask - 1u - second], 1u);
-        }
-        // first token of a match: (pv, a) -> (pv, X); second token: (b, nx) -> (X, nx)
-        const bool counted = on && DIAG != 2 && (is_a ? left_open<MODE>(pv) : right_open<MODE>(self, nx));
-        uint32_t rec;
-        if (is_a) {
-            if (tch) {                            // ... (a', b') (a, b): (b', a) -> (X', X)
-                if (counted) atomicAdd(&hdr_adj[prev_idx * kBatchMax + idx], 1u);
-                rec = lr_idx(pitch, self, prev_idx, 1) | kLogNeg;     // takes back the R count of (a', b')
-            } else {
-                rec = lr_idx(pitch, pv & idmask, idx, 0);
-            }
-        } else {
-            rec = lr_idx(pitch, nx & idmask, idx, 1);
-        }
-        const unsigned long long mk = __ballot(counted);
-        if (counted) dm.stage[__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, wl.cur))] = rec;
-        wl.cur += (uint32_t)__popcll(mk);
-        if (wl.cur >= (uint32_t)kWave) log_flush(wl, dm.stage, dlog, ls, LR, kWave - 1u);
-    }
-    asm volatile("" ::: "memory");
-    uint32_t out[8];
-    unpack8(dm.img[lane], out);
-    return fused_tile_finish<MODE>(out, tt_on, ti, Lm, ABm, Bm, m_live, old_x, old_y, old_z, tile, sout, wave_rm, wrote_sum);
+    // (no tile mark: a fused pass writes every tile's summary to the side array, see DevCtl::marks_all)
+    if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
+    wrote_sum = true;
+    return pack8(out);
 }
 
 // (7 waves per SIMD: the cold instantiation meets it with two spilled registers, which is cheaper than
@@ -3005,17 +2811,13 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                                                                uint32_t *__restrict__ chg, const BatchState *bs,
                                                                uint32_t *hdr_adj, uint32_t *LR, DevCtl *ctl,
                                                                const RankEdge *le, const RankEdge *re,
-                                                               uint32_t *hdr_m, const uint32_t *__restrict__ run_in,
-                                                               uint32_t *dlog, LogState *ls) {
+                                                               uint32_t *hdr_m, const uint32_t *__restrict__ run_in) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
-    // the plain instantiations stage their count deltas as records (delta_log.hip); the HOT ones count in their cache
-    constexpr bool LOG = !HOT;
     __shared__ BatchLutMem lut_mem;
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kLutThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
     __shared__ DeltaCache dc;
-    __shared__ DenseMem dense_mem[LOG ? kLutThreads / kWave : 1];
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2 || !ctl->fused) return;
     // (the instantiation with the (t,t) code only runs for batches that have such a member, like HOT)
@@ -3033,10 +2835,6 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->marks_all = 1;
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
     uint32_t wave_rm = 0;        // uniform
-    DenseMem &dm = dense_mem[LOG ? rfl(threadIdx.x / kWave) : 0u];
-    WaveLog wl;
-    wl.cur = 0; wl.pos = 0; wl.left = 0; wl.spilled = 0;
-    wl.logging = (LOG && ls && dlog) ? rfl(ls->on) : 0u;
     if (tile < n_tiles) {
 
     const uint32_t last_tile = n_tiles - 1;
@@ -3107,14 +2905,9 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             if (DIAG == 3 || DIAG == 5) {    // timing-only build: membership tests, no merge
                 asm volatile("" :: "v"(Am));
             } else if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
-                if (LOG)
-                    outq = fused_tile_dense<MODE, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, m_live, c_init, h, tile_first,
-                                                        old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc,
-                                                        wave_rm, wrote_sum, dm, wl, dlog, ls);
-                else
-                    outq = fused_tile_full<MODE, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, m_live, c_init, h, tile_first,
-                                                       old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
-                                                       wave_rm, wrote_sum);
+                outq = fused_tile_full<MODE, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, m_live, c_init, h, tile_first,
+                                                old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
+                                                wave_rm, wrote_sum);
             }
         }
         // every tile's summary goes to the side array (an unchanged tile's as it was): no tile marks needed
@@ -3131,14 +2924,6 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     }
     }
     if (dc_on) dc_flush(dc, LR);
-    if (LOG) {
-        // the last records, padded to a block of 64; then the rest of the wave's chunk is padding too, so that the
-        // log is whole chunks of valid records
-        if (wl.cur) log_flush(wl, dm.stage, dlog, ls, LR, 0u);
-        if (wl.logging)
-            for (; wl.left; wl.left -= kWave, wl.pos += kWave) dlog[wl.pos + lane] = kLogNull;
-        if (lane == 0 && wl.spilled > 1u) atomicAdd(&ls->spilled, (unsigned long long)(wl.spilled - 1u));
-    }
     if (lane == 0 && wave_rm) atomicAdd(&ctl->rm, wave_rm);
     if (TT) {                           // matches of the (t,t) member: its count is not simply the pair's count
         tt_flush(ti, hdr_m);
@@ -4134,8 +3919,7 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
                         uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible, uint32_t *dlog,
-                        LogState *ls) {
+                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible) {
     if (!n_tiles) return;
     static const int occ[3] = {resident_blocks(k_fused_batch<0, false, false, 0>, kLutThreads),
                                resident_blocks(k_fused_batch<1, false, false, 0>, kLutThreads),
@@ -4146,9 +3930,9 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
 #define MBPE_FUSED_DIAG_CASE(D)                                                                                            \
     if (diag == D && !endbit) {                                                                                            \
         hipLaunchKernelGGL((k_fused_batch<0, false, false, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,        \
-                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in, dlog, ls);                     \
+                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in);                               \
         hipLaunchKernelGGL((k_fused_batch<0, false, true, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,         \
-                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in, dlog, ls);                     \
+                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in);                               \
         return;                                                                                                            \
     }
     MBPE_FUSED_DIAG_CASE(2)
@@ -4159,14 +3943,14 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
 #endif
     MBPE_BY_MODE(endbit, {
         hipLaunchKernelGGL((k_fused_batch<M, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in, dlog, ls);
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
         hipLaunchKernelGGL((k_fused_batch<M, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in, dlog, ls);
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
         if (hot_possible) {
             hipLaunchKernelGGL((k_fused_batch<M, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                               LR, ctl, left_edge, right_edge, hdr_m, run_in, dlog, ls);
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in);
             hipLaunchKernelGGL((k_fused_batch<M, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                               LR, ctl, left_edge, right_edge, hdr_m, run_in, dlog, ls);
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in);
         }
     });
 }

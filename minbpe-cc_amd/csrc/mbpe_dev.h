@@ -200,42 +200,10 @@ __host__ __device__ inline unsigned long long lr_words(uint32_t ids, uint32_t n_
     return 2ull * (n_pairs ? n_pairs : 1u) * lr_pitch(ids);
 }
 
-// is the largest pair of a pass frequent enough for the kernels' HOT instantiation (count deltas cached in LDS)?
-// one occurrence per 8192 live tokens; counts are global, so n_live is the shard's live tokens times the ranks
-__host__ __device__ inline bool dc_wanted(unsigned long long top_count, unsigned long long n_live) {
-    return top_count * 8192ull >= n_live;
-}
-
-// ---- count deltas of a fused pass through a record log (delta_log.hip) -----------------------
-// record = index of the LR cell to add one to; bit 31: subtract one instead; kLogNull: padding
-constexpr uint32_t kLogNull = 0xFFFFFFFFu;
-constexpr uint32_t kLogNeg = 0x80000000u;
-constexpr uint32_t kLogChunk = 1024;               // records a wave reserves in the log at a time (16 stores of 256 bytes)
-constexpr uint32_t kLogBucketShift = 15;           // LR cells per bucket: the counters of one workgroup's LDS (128 KiB)
-constexpr uint32_t kLogBucketCells = 1u << kLogBucketShift;
-constexpr uint32_t kLogMaxBuckets = 2048;          // (2 x 1024 pairs x 32,768 ids; beyond that a pass keeps its atomics)
-constexpr uint32_t kLogMinMatches = 1u << 18;      // passes with fewer matches keep their atomics (option "delta_log" 1)
-struct LogState {
-    uint32_t enabled;        // host: option "delta_log" (0 never, 1 passes with at least kLogMinMatches matches, 2 always)
-    uint32_t on;             // k_log_plan: the fused pass of this sequence logs its count deltas
-    uint32_t n_buckets;
-    uint32_t cap;            // capacity of the log, records
-    uint32_t part_cap;       // capacity of the partition buffer, records
-    uint32_t passes;         // statistics: passes that logged
-    unsigned long long total_records;   // ... records they wrote (padding included)
-    unsigned long long spilled;         // ... records added with atomics because the log was full
-    uint32_t pad0[22];
-    uint32_t n_alloc;        // records reserved so far (waves add kLogChunk at a time); on a line of its own
-    uint32_t pad1[31];
-    uint32_t base[kLogMaxBuckets + 1];  // where a bucket's region starts in the partition buffer
-    uint32_t fill[kLogMaxBuckets];      // records placed in it so far
-};
-
 constexpr uint32_t kErrTableFull   = 1u;
 constexpr uint32_t kErrNegCount    = 2u;
 constexpr uint32_t kErrMissingPair = 4u;
 constexpr uint32_t kErrCountRange  = 8u;   // a pair count does not fit 31 bits (the table keeps a "present" flag in bit 31)
-constexpr uint32_t kErrLog         = 16u;  // a bucket of the delta log outgrew its bound (never expected)
 
 // packed argmax word: (count << 32) | ~key  -- larger is better:
 // count descending, then key ascending == (first, second) ascending,
@@ -326,19 +294,10 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok0, const uint16_t *tok1
                        uint32_t *LR, const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge,
                        uint32_t endbit, int n_cus, const uint32_t *run_in, int hot_possible = 1);
 // large batch (ctl->fused): count the deltas and write the merged stream to the other buffer
-// dlog / ls (optional): the record log of delta_log.hip; with ls->on (launch_log_plan, before this) the plain
-// instantiations log their count deltas instead of adding them to LR, and launch_log_consume must follow
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
                         uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible = 1,
-                        uint32_t *dlog = nullptr, LogState *ls = nullptr);
-// delta_log.hip: decide whether the sequence's fused pass logs (and lay out the partition buffer); after the pass,
-// partition the log by LR bucket and count every bucket in LDS into LR
-size_t log_state_bytes();
-void launch_log_plan(hipStream_t s, const DevCtl *ctl, const BatchState *bs, LogState *ls);
-void launch_log_consume(hipStream_t s, const uint32_t *dlog, uint32_t *part, uint32_t *LR, LogState *ls, DevCtl *ctl,
-                        int n_cus);
+                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible = 1);
 // k_delta_max + k_validate + k_apply_batch
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                          uint32_t *LR, uint32_t id_upper);

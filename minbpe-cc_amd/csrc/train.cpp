@@ -210,11 +210,6 @@ struct mbpe_ctx {
     int64_t opt_first_batches = 0;  // `first` mode: 1 = pairs whose counts no other pair shares are merged in batches too
                                     //   (no faster on text: words make chains of pairs with one count)
     int64_t opt_first = 0;          // 1: `first` tie-break (insertion order, PairCount.h:65-74) instead of lexical
-    // count deltas of the fused passes through a record log instead of scattered atomics (delta_log.hip)
-    int64_t opt_delta_log = 1;      // 0: the fused pass adds its count deltas to LR with global atomics
-    int64_t opt_delta_log_cap = 0;  // capacity of the log in records (0: by the size of the stream; tests force it small)
-    uint32_t *dlog = nullptr, *dpart = nullptr;
-    LogState *ls = nullptr;
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     // multi-GPU: what the selection of the sequence in flight decided (k_done, k_limit, batch_n, commit_n of DevCtl),
     // read back while its stream pass runs, so that exactly the cells the batch can touch are exchanged
@@ -310,7 +305,6 @@ void free_training(mbpe_ctx *c) {
     tfree(c, c->bp); tfree(c, c->ctl); tfree(c, c->best); tfree(c, c->xb); tfree(c, c->xb0);
     tfree(c, c->d_left); tfree(c, c->d_right); tfree(c, c->bs); tfree(c, c->sel); tfree(c, c->seq_flags); tfree(c, c->run_in);
     tfree(c, c->first_state);
-    tfree(c, c->dlog); tfree(c, c->dpart); tfree(c, c->ls);
     c->LR = nullptr;
     c->pending = 0;
     c->begun = false;
@@ -514,8 +508,6 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "chunk_barrier") c->opt_barrier = value < 0 ? -1 : value != 0;       // (read by the next mbpe_train_begin)
     else if (n == "first_batches") c->opt_first_batches = value != 0;
     else if (n == "sel_cap") c->opt_sel_cap = std::min<int64_t>(std::max<int64_t>(64, value), kSelCap);
-    else if (n == "delta_log") c->opt_delta_log = value < 0 ? 0 : value > 2 ? 2 : value;     // (read by the next mbpe_train_begin)
-    else if (n == "delta_log_cap") c->opt_delta_log_cap = std::max<int64_t>(0, value);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
 }
@@ -740,25 +732,6 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     c->hdr_adj = c->hdr_m + kBatchMax;
     c->LR = c->xb + c->hdr_words + c->hdrb_words;
     HIPCHK(tmalloc(c, &c->bs, sizeof(BatchState)));
-    {
-        // The record log of the fused passes.  A pass that logs holds at most n_live / 8 matches (its top pair
-        // occurs less than once per 8192 live tokens, kernels' dc_wanted, and a batch has at most 1024 pairs); the
-        // benchmark corpus has one per 80.  Log: two records per match + padding; partition buffer: its regions are
-        // bounds (three records per match).  A pass that would not fit keeps its atomics (k_log_plan), records that
-        // find the log full are added with atomics (log_flush): sizes only decide speed.  1/16 and 1/8 of the slots
-        // (1.1 + 2.1 GB for a 4 GiB corpus), at least 8192 chunks (32 MB).
-        uint64_t log_cap = std::max<uint64_t>(c->n_slots / 16, 8192ull * kLogChunk);     // (every wave pads a chunk)
-        if (c->opt_delta_log_cap > 0) log_cap = (uint64_t)c->opt_delta_log_cap;
-        log_cap = std::min<uint64_t>(log_cap, 0xC0000000ull);
-        const uint64_t part_cap = std::min<uint64_t>(std::max<uint64_t>(c->n_slots / 8, 8192ull * kLogChunk), 0xC0000000ull);
-        HIPCHK(tmalloc(c, &c->dlog, (size_t)(log_cap + kLogChunk) * 4));
-        HIPCHK(tmalloc(c, &c->dpart, (size_t)part_cap * 4));
-        HIPCHK(tmalloc(c, &c->ls, sizeof(LogState)));
-        HIPCHK(hipMemsetAsync(c->ls, 0, sizeof(LogState), c->stream));
-        const uint32_t init[5] = {(uint32_t)c->opt_delta_log, 0u, 0u, (uint32_t)log_cap, (uint32_t)part_cap};
-        static_assert(offsetof(LogState, part_cap) == 16, "enabled, on, n_buckets, cap, part_cap lead the struct");
-        HIPCHK(hipMemcpyAsync(c->ls, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    }
     HIPCHK(tmalloc(c, &c->sel, sizeof(SelList)));
     HIPCHK(tmalloc(c, &c->run_in, ((size_t)c->n_tiles + 64) * 4));
     HIPCHK(tmalloc(c, &c->seq_flags, 4096 * 4));
@@ -935,13 +908,13 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
                  multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1, c->offsets + c->n_tiles, c->run_in, c->bs, c->hot_possible);
     launch_scan_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
                       c->ctl, le, re, endbit, c->n_cus, c->run_in, c->hot_possible);
-    launch_log_plan(c->stream, c->ctl, c->bs, c->ls);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev_f[2 * ev_slot], c->stream);
     launch_fused_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->bs, c->hdr_adj, c->LR,
-                       c->ctl, le, re, endbit, c->n_cus, c->hdr_m, c->run_in, c->hot_possible, c->dlog, c->ls);
-    if (ev_slot >= 0) (void)hipEventRecord(c->kev_f[2 * ev_slot + 1], c->stream);
-    launch_log_consume(c->stream, c->dlog, c->dpart, c->LR, c->ls, c->ctl, c->n_cus);
-    if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
+                       c->ctl, le, re, endbit, c->n_cus, c->hdr_m, c->run_in, c->hot_possible);
+    if (ev_slot >= 0) {
+        (void)hipEventRecord(c->kev_f[2 * ev_slot + 1], c->stream);
+        (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
+    }
 }
 
 static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge exchange
@@ -1376,16 +1349,6 @@ int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
     for (int i = 0; i < 8; ++i) c->stats.size_hist[i] = c->begun ? c->h_ctl.size_hist[i] : 0;
     c->stats.n_skipped = c->begun ? c->h_ctl.n_skipped : 0;
     c->stats.n_skip_cut = c->begun ? c->h_ctl.n_skip_cut : 0;
-    c->stats.n_log_passes = 0;
-    c->stats.log_records = c->stats.log_spilled = 0;
-    if (c->begun && c->ls) {
-        LogState head;       // (the leading scalars only)
-        HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipMemcpy(&head, c->ls, offsetof(LogState, pad0), hipMemcpyDeviceToHost));
-        c->stats.n_log_passes = head.passes;
-        c->stats.log_records = head.total_records;
-        c->stats.log_spilled = head.spilled;
-    }
     *out = c->stats;
     return MBPE_OK;
 }

@@ -50,8 +50,7 @@ class Stats(ctypes.Structure):
         ("fused_launches", ctypes.c_uint32), ("ms_fused_kernel", ctypes.c_float), ("fused_slots", ctypes.c_uint64),
         ("n_sel_retry", ctypes.c_uint32), ("adapt_limit", ctypes.c_uint32), ("n_sel_blocks", ctypes.c_uint64), ("size_hist", ctypes.c_uint32 * 8),
         ("n_skipped", ctypes.c_uint32), ("n_skip_cut", ctypes.c_uint32),
-        ("exchange_words", ctypes.c_uint64), ("exchanges", ctypes.c_uint32), ("n_log_passes", ctypes.c_uint32),
-        ("log_records", ctypes.c_uint64), ("log_spilled", ctypes.c_uint64),
+        ("exchange_words", ctypes.c_uint64), ("exchanges", ctypes.c_uint32), ("pad_", ctypes.c_uint32),
     ]
 
     def as_dict(self):
