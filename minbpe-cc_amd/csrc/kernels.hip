@@ -379,6 +379,27 @@ __device__ __forceinline__ PcCheck pc_check(const uint32_t *hist, unsigned long 
     return r;
 }
 
+// The 4 pairs that start in dword w (wn = the following dword of the byte stream), 4.75 vector instructions per pair
+// instead of 8: z = the stream shifted by one byte (v_alignbit), y = w ^ z (byte k of y = first ^ second of pair k),
+// z7 = z & 0x7F7F7F7F; then per pair ONE v_perm_b32 builds the 15-bit word index ((second & 0x7F) << 8 | first ^
+// second: exactly bin ^= bin >> 8; word = bin & 0x7FFF), the LDS address is that index scaled by the atomic's
+// pointer arithmetic, and v_bfe + v_mad give the increment: 1, or 0x10000 when the second byte's top bit is set (=
+// bin >> 15).  The two inline-asm instructions keep the compiler from turning the increment into compare + select
+// (vcc hazards, s_nop: round 2's attempt).  A/B: tools/pc_variants.hip, profiles/r03_pair_count_ab.md.
+__device__ __forceinline__ void pc_lean_pairs(uint32_t *hist, uint32_t w, uint32_t wn, uint32_t k0xffff) {
+    const uint32_t z = __builtin_amdgcn_alignbit(wn, w, 8);
+    const uint32_t y = w ^ z;
+    const uint32_t z7 = z & 0x7F7F7F7Fu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t word = __builtin_amdgcn_perm(z7, y, 0x0C0C0000u | ((4u + k) << 8) | (uint32_t)k);
+        uint32_t top, inc;
+        asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(top) : "v"(z), "n"(8 * k + 7));
+        asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc) : "v"(top), "s"(k0xffff));
+        atomicAdd(&hist[word], inc);
+    }
+}
+
 // Counts the pairs that start in the full 16-byte vectors [begin, end) of this workgroup
 // (begin, end: multiples of the iteration size from the workgroup's first vector).  VPL vectors per
 // lane and iteration; SWEEPS: sweep every kPcEpochIters iterations (VPL must be 1).  Returns the number
@@ -432,6 +453,12 @@ __device__ __forceinline__ uint32_t pc_count_range(uint32_t *hist, uint32_t *__r
             const uint32_t w[5] = {cq[u].x, cq[u].y, cq[u].z, cq[u].w, nb};
             if (__ballot(valid != 0xFFFFu) == 0ull) {
                 // every pair of every lane counts: no per-pair predicate
+#if !defined(MBPE_PC_NOHASH) && !defined(MBPE_PC_PLAIN)
+                uint32_t k0xffff;
+                asm volatile("s_mov_b32 %0, 0xffff" : "=s"(k0xffff));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pc_lean_pairs(hist, w[i], w[i + 1], k0xffff);
+#else
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int wi = i >> 2, sh = 8 * (i & 3);
@@ -443,6 +470,7 @@ __device__ __forceinline__ uint32_t pc_count_range(uint32_t *hist, uint32_t *__r
 #endif
                     atomicAdd(&hist[bin & 0x7FFFu], 1u + (bin >> 15) * 0xFFFFu);
                 }
+#endif
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {

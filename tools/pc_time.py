@@ -1,8 +1,11 @@
-"""30 launches of the pair-count scan through the C-ABI on the 4 GiB corpus (clock ramp, box-to-box spread);
-MBPE_LIB selects a variant library built by tools/mkvar.sh.  Results: profiles/r02_pair_count_ab.md."""
+"""Launches of the pair-count scan through the C-ABI: 30 on the 4 GiB SplitMix64 corpus (clock ramp, box-to-box
+spread) and 30 on 446 MB of text (shakespeare x 400: few distinct first bytes, what the bank hash is for).
+MBPE_LIB selects a variant library built by tools/mkvar.sh.  Results: profiles/r0N_pair_count_ab.md."""
 import os, sys, json
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "minbpe-cc_amd", "python"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "minbpe-cc_amd", "python"))
+sys.path.insert(0, ROOT)
+import numpy as np
 import torch, mbpe
 from bench import splitmix64_device
 dev = torch.device("cuda", 0)
@@ -15,4 +18,15 @@ ms = []
 for i in range(30):
     tr.pair_count_u8(want_table=False)
     ms.append(round(tr.stats()["ms_pair_count"], 3))
-print(os.environ.get("MBPE_LIB", "default"), ms)
+tag = os.environ.get("MBPE_LIB", "default")
+print(tag, "random 4 GiB", ms, "mean of launches 11-30: %.4f" % (sum(ms[10:]) / 20.0), flush=True)
+del keep, corpus
+text = open(os.path.join(ROOT, "tests", "golden", "data", "shakespeare.txt"), "rb").read() * 400
+t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+torch.cuda.synchronize()
+tr.load_corpus_device(t.data_ptr(), len(text), keep=t)
+ms = []
+for i in range(30):
+    tr.pair_count_u8(want_table=False)
+    ms.append(round(tr.stats()["ms_pair_count"], 4))
+print(tag, "text %d bytes" % len(text), ms, "mean of launches 11-30: %.4f" % (sum(ms[10:]) / 20.0), flush=True)
