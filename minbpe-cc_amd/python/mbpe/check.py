@@ -166,3 +166,59 @@ def dense_table_matches_recount(tr, torch, device):
         nonzero += int(((cells[lo:lo + step] & 0x7FFFFFFF) != 0).sum())
     return {"ok": present and same and nonzero == int(u.numel()), "pairs_in_stream": int(u.numel()),
             "nonzero_cells": nonzero, "counts_equal": same, "all_present": present}
+
+
+def recount_cells(tr, torch, device, vshift, slots_per_piece=1 << 27):
+    """The adjacent pairs of the live stream counted from scratch into a dense array laid out like the
+    library's dense pair table (tiles of 32 x 32 cells), piece by piece so that a 4 GiB stream needs no
+    more than a few GB of scratch.  int32[1 << 2 * vshift]."""
+    _, n_slots, _, _, _ = tr.stream_device()
+    hist = torch.zeros(1 << (2 * vshift), dtype=torch.int32, device=device)
+    prev_tok, prev_end = None, False
+    for lo in range(0, n_slots, slots_per_piece):
+        toks, ends = live_tokens(tr, torch, device, lo, lo + slots_per_piece)
+        if toks.numel() == 0:
+            continue
+        toks = toks.long()
+        if prev_tok is not None:          # the pair that straddles the pieces
+            toks = torch.cat([prev_tok.view(1), toks])
+            if ends is not None:
+                ends = torch.cat([torch.tensor([prev_end], dtype=torch.bool, device=device), ends])
+        a, b = toks[:-1], toks[1:]
+        if ends is not None:
+            keep = ~ends[:-1]
+            a, b = a[keep], b[keep]
+        idx = ((((a >> 5) << (vshift - 5)) | (b >> 5)) << 10) | ((a & 31) << 5) | (b & 31)
+        del a, b
+        hist += torch.bincount(idx, minlength=hist.numel()).to(torch.int32)
+        del idx
+        prev_tok = toks[-1].clone()
+        prev_end = bool(ends[-1]) if ends is not None else False
+        del toks
+    return hist
+
+
+def argmax_at_checkpoint(tr, torch, device):
+    """At a host synchronisation point of a training run with the dense pair table: (i) the incrementally
+    maintained table equals a recount of the live stream, cell by cell; (ii) the merge the trainer commits
+    next is the argmax of the RECOUNTED table under (count descending, first ascending, second ascending) --
+    CompareLexicalOrder, PairCount.h:194-207, get_top_pair_count :262-269.  Runs one merge (train_steps(1))."""
+    ptr, vshift = tr.table_device()
+    cells = _as_tensor(torch, ptr, 1 << (2 * vshift), torch.int32, device)
+    hist = recount_cells(tr, torch, device, vshift)
+    table_ok = bool(((cells & 0x7FFFFFFF) == hist).all())
+    cmax = int(hist.max())
+    e = torch.nonzero(hist == cmax).view(-1)                 # cells holding the maximum
+    tile, w = e >> 10, e & 1023
+    first = ((tile >> (vshift - 5)) << 5) | (w >> 5)
+    second = ((tile & ((1 << (vshift - 5)) - 1)) << 5) | (w & 31)
+    key = (first << 16) | second
+    k = int(key.min())
+    del hist, e, tile, w, first, second, key
+    n_before = len(tr.train_result()[0])
+    tr.train_steps(1)
+    merges, counts = tr.train_result()
+    got = (int(merges[n_before][0]), int(merges[n_before][1]), int(counts[n_before])) if len(merges) > n_before else None
+    want = (k >> 16, k & 0xFFFF, cmax)
+    return {"merge": n_before, "table_equals_recount": table_ok, "argmax_of_recount": list(want),
+            "committed": list(got) if got else None, "ok": bool(table_ok and got == want and cmax > 0)}

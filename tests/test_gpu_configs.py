@@ -108,6 +108,35 @@ def test_config4_full_vocab_properties_1gib(dev):
     assert (int(m[0][0]), int(m[0][1])) == (first >> 8, first & 0xFF) and int(c[0]) == int(table[first])
 
 
+def test_config4_merge_order_at_checkpoints_1gib(dev):
+    """The ORDER of merges deep into a full-size run, not only its end state: at checkpoints spread over a training
+    of 1 GiB of the benchmark corpus to vocab 32,000 -- the last ones beyond merge 28,000, where batches are small,
+    selections retry and compactions have happened -- the stream is recounted from scratch on the device; the
+    incrementally maintained table must equal the recount cell by cell, and the merge the trainer commits next
+    must be the argmax of the RECOUNTED table under (count desc, first asc, second asc): CompareLexicalOrder,
+    PairCount.h:194-207; get_top_pair_count, :262-269."""
+    from bench import splitmix64_device
+    n = 1 << 30
+    keep, corpus = splitmix64_device(42, n, dev)
+    torch.cuda.synchronize()
+    total = 32000 - 256
+    with mbpe.Trainer(0) as tr:
+        tr.load_corpus_device(corpus.data_ptr(), n, keep=keep)
+        tr.train_begin(32000)
+        seen = []
+        for at in (0, 700, 5000, 16384, 24000, 28500, 30900, 31700):
+            have = len(tr.train_result()[0])
+            if at > have:
+                assert tr.train_steps(at - have) == at - have
+            r = C.argmax_at_checkpoint(tr, torch, dev)
+            assert r["ok"], r
+            seen.append(r["merge"])
+        assert seen == [0, 700, 5000, 16384, 24000, 28500, 30900, 31700]
+        tr.train_steps(total)
+        m, c = tr.train_result()
+        assert len(m) == total and C.counts_nonincreasing(c)
+
+
 def test_library_rccl_next_to_torch_distributed(dev):
     """bench.py at N > 1 initialises torch.distributed's NCCL (= RCCL) backend first and the library's own
     communicator (dlopen of librccl.so.1, ncclCommInitRank) second, in the same process.  Both must work
