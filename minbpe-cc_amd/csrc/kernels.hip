@@ -143,6 +143,18 @@ __device__ __forceinline__ bool dc_wanted(unsigned long long top_count, unsigned
     return top_count * 8192ull >= n_live;
 }
 
+// The stream kernels come in a plain and a HOT instantiation and each pass is done by the one the data ask for
+// (dc_wanted).  The host does not even launch the HOT ones while it can prove them unnecessary (hot_launched 0): should
+// the proof ever be wrong, the pass would silently not happen -- so the plain instantiation says so instead.
+template <bool HOT>
+__device__ __forceinline__ bool hot_mismatch(unsigned long long top_count, const DevCtl *ctl, int hot_launched) {
+    const bool want = dc_wanted(top_count, ctl->n_live * ctl->n_ranks);
+    if (want == HOT) return false;
+    if (!HOT && !hot_launched && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicOr(const_cast<uint32_t *>(&ctl->err), kErrHotSkipped);
+    return true;
+}
+
 __device__ __forceinline__ uint32_t hash_key(uint32_t k) {
     k *= 0x9E3779B1u;
     k ^= k >> 15;
@@ -1474,7 +1486,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
                                                          uint32_t X, uint32_t *LR, DevCtl *ctl,
                                                          uint32_t *m_adj, const RankEdge *le,
                                                          const RankEdge *re, int seq,
-                                                         const uint32_t *__restrict__ run_in) {
+                                                         const uint32_t *__restrict__ run_in, int hot_launched) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     __shared__ DeltaCache dc;
     const uint32_t lane = lane_id();
@@ -1495,7 +1507,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
     const uint32_t key = ~(uint32_t)best;
     const uint32_t a = rfl(key >> 16), b = rfl(key & 0xFFFFu);
     // two instantiations are launched: the one with the delta cache only works on a frequent pair
-    if (dc_wanted(best >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;
+    if (hot_mismatch<HOT>(best >> 32, ctl, hot_launched)) return;
     constexpr bool dc_on = HOT;
     if (dc_on) { dc_init(dc); __syncthreads(); }
 
@@ -2591,7 +2603,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
                                                               uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
                                                               const DevCtl *ctl, const RankEdge *le,
                                                               const RankEdge *re,
-                                                              const uint32_t *__restrict__ run_in) {
+                                                              const uint32_t *__restrict__ run_in, int hot_launched) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     __shared__ BatchLutMem lut_mem;
     const uint32_t lane = lane_id();
@@ -2604,7 +2616,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     __shared__ TTInfo ti;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     const uint32_t pitch = rfl(lr_pitch(256u + ctl->k_done));
-    if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
+    if (hot_mismatch<HOT>(bs->packed[0] >> 32, ctl, hot_launched)) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
     BatchLut lut(&lut_mem, bs);
@@ -2839,7 +2851,8 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                                                                uint32_t *__restrict__ chg, const BatchState *bs,
                                                                uint32_t *hdr_adj, uint32_t *LR, DevCtl *ctl,
                                                                const RankEdge *le, const RankEdge *re,
-                                                               uint32_t *hdr_m, const uint32_t *__restrict__ run_in) {
+                                                               uint32_t *hdr_m, const uint32_t *__restrict__ run_in,
+                                                               int hot_launched) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     __shared__ BatchLutMem lut_mem;
     const uint32_t lane = lane_id();
@@ -2854,7 +2867,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     uint16_t *dst = ctl->cur ? tok0 : tok1;
     const uint32_t X0 = 256u + ctl->k_done;
-    if (dc_wanted(bs->packed[0] >> 32, ctl->n_live * ctl->n_ranks) != HOT) return;     // (see k_merge)
+    if (hot_mismatch<HOT>(bs->packed[0] >> 32, ctl, hot_launched)) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
     BatchLut lut(&lut_mem, bs);
@@ -3884,22 +3897,22 @@ void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileS
     static const int diag = getenv("MBPE_MERGE_DIAG") ? atoi(getenv("MBPE_MERGE_DIAG")) : 0;
     if (diag == 1 && !endbit) {
         hipLaunchKernelGGL((k_merge<0, false, 1>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq, run_in);
+                           m_adj, left_edge, right_edge, seq, run_in, hot_possible);
         return;
     }
     if (diag == 2 && !endbit) {
         hipLaunchKernelGGL((k_merge<0, false, 2>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq, run_in);
+                           m_adj, left_edge, right_edge, seq, run_in, hot_possible);
         return;
     }
 #endif
     // (both instantiations: each returns at once unless the pair's frequency is its case)
     MBPE_BY_MODE(endbit, {
         hipLaunchKernelGGL((k_merge<M, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq, run_in);
+                           m_adj, left_edge, right_edge, seq, run_in, hot_possible);
         if (hot_possible)
             hipLaunchKernelGGL((k_merge<M, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR,
-                               ctl, m_adj, left_edge, right_edge, seq, run_in);
+                               ctl, m_adj, left_edge, right_edge, seq, run_in, hot_possible);
     });
 }
 
@@ -3958,9 +3971,9 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
 #define MBPE_FUSED_DIAG_CASE(D)                                                                                            \
     if (diag == D && !endbit) {                                                                                            \
         hipLaunchKernelGGL((k_fused_batch<0, false, false, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,        \
-                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in);                               \
+                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);                               \
         hipLaunchKernelGGL((k_fused_batch<0, false, true, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,         \
-                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in);                               \
+                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);                               \
         return;                                                                                                            \
     }
     MBPE_FUSED_DIAG_CASE(2)
@@ -3971,14 +3984,14 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
 #endif
     MBPE_BY_MODE(endbit, {
         hipLaunchKernelGGL((k_fused_batch<M, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
         hipLaunchKernelGGL((k_fused_batch<M, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in);
+                           LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
         if (hot_possible) {
             hipLaunchKernelGGL((k_fused_batch<M, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                               LR, ctl, left_edge, right_edge, hdr_m, run_in);
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
             hipLaunchKernelGGL((k_fused_batch<M, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                               LR, ctl, left_edge, right_edge, hdr_m, run_in);
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
         }
     });
 }
@@ -3997,7 +4010,7 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
 #define MBPE_SCAN_DIAG_CASE(D)                                                                                             \
     if (diag == D && !endbit) {                                                                                            \
         hipLaunchKernelGGL((k_scan_batch<0, false, false, D>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs,       \
-                           hdr_m, hdr_adj, LR, ctl, left_edge, right_edge, run_in);                                        \
+                           hdr_m, hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible);                                        \
         return;                                                                                                            \
     }
     MBPE_SCAN_DIAG_CASE(1)
@@ -4008,14 +4021,14 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
 #endif
     MBPE_BY_MODE(endbit, {
         hipLaunchKernelGGL((k_scan_batch<M, false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj,
-                           LR, ctl, left_edge, right_edge, run_in);
+                           LR, ctl, left_edge, right_edge, run_in, hot_possible);
         hipLaunchKernelGGL((k_scan_batch<M, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj,
-                           LR, ctl, left_edge, right_edge, run_in);
+                           LR, ctl, left_edge, right_edge, run_in, hot_possible);
         if (hot_possible) {
             hipLaunchKernelGGL((k_scan_batch<M, true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m,
-                               hdr_adj, LR, ctl, left_edge, right_edge, run_in);
+                               hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible);
             hipLaunchKernelGGL((k_scan_batch<M, true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m,
-                               hdr_adj, LR, ctl, left_edge, right_edge, run_in);
+                               hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible);
         }
     });
 }

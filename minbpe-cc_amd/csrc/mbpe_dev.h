@@ -204,6 +204,8 @@ constexpr uint32_t kErrTableFull   = 1u;
 constexpr uint32_t kErrNegCount    = 2u;
 constexpr uint32_t kErrMissingPair = 4u;
 constexpr uint32_t kErrCountRange  = 8u;   // a pair count does not fit 31 bits (the table keeps a "present" flag in bit 31)
+constexpr uint32_t kErrHotSkipped  = 16u;  // a pass needed the frequent-pair instantiation of a stream kernel, which the host
+                                           //   had ruled out and not launched (kernels.hip: hot_mismatch)
 
 // packed argmax word: (count << 32) | ~key  -- larger is better:
 // count descending, then key ascending == (first, second) ascending,

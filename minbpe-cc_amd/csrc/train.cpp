@@ -206,6 +206,7 @@ struct mbpe_ctx {
     int64_t opt_threshold_select = 1;   // 0: always select with the bound-walking kernel
     int64_t opt_dense_table = -1;   // -1 auto / 1: dense pair table when vocab <= 32,768; 0: always hashed
     int hot_possible = 1;           // may a batch of the next group of sequences hold a "frequent" pair (kernels' dc_wanted)?
+    unsigned long long last_top = ~0ull;   // count of the latest merge the host has seen: bounds every later count
     int64_t opt_barrier = -1;       // chunk ends as barrier slots: -1 when the ids need 16 bits, 0 never, 1 always
     int64_t opt_first_batches = 0;  // `first` mode: 1 = pairs whose counts no other pair shares are merged in batches too
                                     //   (no faster on text: words make chains of pairs with one count)
@@ -286,9 +287,9 @@ int sync_ctl(mbpe_ctx *c) {
     if (getenv("MBPE_SCAN_DIAG") || getenv("MBPE_MERGE_DIAG") || getenv("MBPE_FUSED_DIAG")) c->h_ctl.err = 0;   // timing-only kernels break the counts
 #endif
     if (c->h_ctl.err) {
-        char buf[160];
+        char buf[200];
         snprintf(buf, sizeof(buf), "device error flags 0x%x (1=pair table full, 2=negative count, 4=missing pair, "
-                                   "8=a pair occurs 2^31 times or more)",
+                                   "8=a pair occurs 2^31 times or more, 16=a stream pass was skipped)",
                  c->h_ctl.err);
         mbpe_host::set_last_error(buf);
         return MBPE_ERR_OVERFLOW;
@@ -502,7 +503,12 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "threshold_select") c->opt_threshold_select = value != 0;
     else if (n == "conflict_resolution") {
         if (value != 0 && value != 1) { mbpe_host::set_last_error("conflict_resolution: 0 = first, 1 = lexical"); return MBPE_ERR_ARG; }
-        if (c->begun) { mbpe_host::set_last_error("conflict_resolution must be set before mbpe_train_begin"); return MBPE_ERR_STATE; }
+        // (only while a training is under way: a finished one, or one whose table ran empty, can be followed by
+        //  another mbpe_train_begin on the same corpus with the other tie-break)
+        if (c->begun && (c->pending || (c->k < c->n_target && !c->exhausted))) {
+            mbpe_host::set_last_error("conflict_resolution cannot change in the middle of a training");
+            return MBPE_ERR_STATE;
+        }
         c->opt_first = value == 0;
     }
     else if (n == "chunk_barrier") c->opt_barrier = value < 0 ? -1 : value != 0;       // (read by the next mbpe_train_begin)
@@ -518,6 +524,9 @@ int mbpe_load_corpus(mbpe_ctx *c, const uint8_t *text, uint64_t n_bytes, const u
     HIPCHK(hipSetDevice(c->device));
     free_training(c);
     free_corpus(c);
+    // (the training buffers of a corpus of another size would not be handed out again: give them back before the
+    //  new corpus is allocated, not only inside the next mbpe_train_begin)
+    if (n_bytes != c->n_bytes || (chunk_off != nullptr) != c->chunked) pool_trim(c);
     c->n_bytes = n_bytes;
     c->chunked = chunk_off != nullptr;
     c->n_chunks = chunk_off ? n_chunks : 1;
@@ -798,6 +807,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
 // maximal count never rises, and n_live falls by at most one count per merge, so for the next `merges` merges
 // HOT stays impossible while top * 8192 < (n_live - merges * top) * ranks: then it is not even launched.
 static void update_hot_possible(mbpe_ctx *c, unsigned long long top_count, uint64_t merges) {
+    c->last_top = top_count;
     if (c->comm_external) { c->hot_possible = 1; return; }     // (the caller drives the sequences one by one)
     const unsigned long long live = c->h_ctl.n_live;
     const unsigned long long eaten = merges * top_count;
@@ -1028,6 +1038,8 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
             }
         }
         c->k_upper = c->k;
+        // (for THIS group: the "batch" / "max_batch" options may have changed since the bound was last computed)
+        update_hot_possible(c, c->last_top, (uint64_t)group * kBatchMax);
         const uint32_t batches_before = c->h_ctl.n_batches, singles_before = c->h_ctl.cut_single;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         uint32_t launched = 0;

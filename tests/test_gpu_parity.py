@@ -672,3 +672,33 @@ def test_fused_pass_uniform_bytes(tr, chunked):
         data[data == 0] = 1                # (a NUL-led chunk that parses as a number is one token in the oracle's stream and
     off = _random_chunks(rng, n, 40) if chunked else None      #  inert bytes in the library's: Tokenizer.h:86-93)
     _step_parity(tr, data, off, 256 + 260, stride=90, fused_min=2)
+
+
+def test_batch_option_changed_after_begin_on_flat_counts(tr):
+    """The host does not launch the frequent-pair (HOT) instantiations of the stream kernels while it can prove that no
+    pair becomes frequent (one occurrence per 8192 live tokens) within the merges of the next group of sequences.  The
+    proof has to hold for the group that really runs.  "batch" 1 at mbpe_train_begin: the bound covers 1024 merges;
+    then "batch" 64 and "max_batch" 32: the first group is 64 sequences of up to 32 merges.  On a flat-count corpus
+    (uniform over 116 symbols: the top pair occurs once per 9434 tokens) the threshold is crossed after ~1250 merges:
+    inside that group, beyond the bound.  (Without the per-group bound the pass is skipped; the plain instantiation
+    now also flags that: kErrHotSkipped.)"""
+    rng = np.random.default_rng(5)
+    S, n = 116, 1_500_000
+    data = rng.integers(1, S + 1, size=n, dtype=np.uint8)
+    pairs = np.bincount(data[:-1].astype(np.int64) * 256 + data[1:], minlength=65536)
+    top = int(pairs.max())
+    assert top * 9216 < n, "not frequent within the 1024 merges the first bound covers"
+    assert top * 8192 >= n - 1900 * top, "... but frequent within the first 64 x 32 merges"
+    vocab = 256 + 2300
+    want_m, want_c = O.train(data, vocab)
+    try:
+        tr.set_option("batch", 1)
+        tr.load_corpus(data)
+        tr.train_begin(vocab)
+        tr.set_option("batch", 64)
+        tr.set_option("max_batch", 32)
+        assert tr.train_steps(vocab - 256) == vocab - 256
+        m, c = tr.train_result()
+    finally:
+        _defaults(tr)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
