@@ -23,6 +23,9 @@ PATTERNS = {"basic": "", "gpt2": GPT2_SPLIT_PATTERN, "gpt4": GPT4_SPLIT_PATTERN}
 
 
 def build(force=False):
+    # (BPE_ORACLE_LIB: another build of the same source, e.g. `make asan`'s libbpe_oracle_asan.so)
+    if os.environ.get("BPE_ORACLE_LIB"):
+        return os.environ["BPE_ORACLE_LIB"]
     src = os.path.join(_HERE, "bpe_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "libbpe_oracle.so"], stdout=subprocess.DEVNULL)

@@ -22,6 +22,14 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.mbpe_version()
 
 
+def test_library_is_built_from_this_tree():
+    # build() compiles from source unless the binary carries the hash of exactly these sources (mbpe_version)
+    import __graft_entry__ as ge
+    want = ge.source_hash()
+    assert ge.lib_hash() == want
+    assert ("mbpe-src:" + want).encode() in mbpe.lib().mbpe_version()
+
+
 def _has_gpu():
     import torch
     return torch.cuda.is_available()

@@ -168,3 +168,24 @@ def test_incremental_counts_stay_exact():
         for x, y in zip(toks[:-1], toks[1:]):
             recount[(int(x), int(y))] = recount.get((int(x), int(y)), 0) + 1
         assert {k: v for k, v in st.table_dict().items() if v} == recount
+
+
+def test_oracle_known_answers_under_asan_ubsan():
+    """SURVEY.md section 5 (sanitizers on the host code): the oracle built with -fsanitize=address,undefined
+    (oracle/Makefile `asan`) runs the known-answer tests, the NUL quirk, the tiny inputs and the incremental-count
+    check of this file in a child interpreter; any sanitizer report fails it."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    orc = os.path.join(os.path.dirname(here), "oracle")
+    subprocess.check_call(["make", "-C", orc, "asan"], stdout=subprocess.DEVNULL)
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    libubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"]).decode().strip()
+    env = dict(os.environ, BPE_ORACLE_LIB=os.path.join(orc, "libbpe_oracle_asan.so"),
+               LD_PRELOAD=libasan + ":" + libubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
+                        "kat or nul_quirk or empty_and_single or incremental_counts"],
+                       env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "passed" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
