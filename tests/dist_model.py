@@ -208,6 +208,224 @@ class Shard:
         edges = [[int(v) for v in xb[2 + 8 * r:10 + 8 * r]] for r in range(self.world)]
         self.compose(edges)
 
+    # ---- a BATCH SEQUENCE: what the product runs per stream pass (train.cpp seq_stage_a/b/c) -------------
+    # select (identical on every rank: replicated table) -> one pass over the shard that counts the deltas of
+    # every pair of the batch -> ONE sum all-reduce of [header][m_j, ADJ][LR rows L_j, R_j of lr_pitch(ids) cells]
+    # = header + batch header + 2 * n * pitch words, exactly -> validate (longest prefix the one-at-a-time loop
+    # would have chosen in this order) -> apply the prefix's deltas -> rewrite the shard -> edges all-reduce.
+    BATCH_MAX = 16                  # the model's kBatchMax (row pitch of ADJ, size of the m_j block)
+
+    @staticmethod
+    def lr_pitch(ids):
+        return (ids + 63) & ~63
+
+    def select_batch(self, limit):
+        """k_sel_pick without the pass-over of dependent candidates: maxima in argmax order while each is
+        independent of the earlier members ((c,d) after (a,b): d != a and c != b), has a count, and is no (t,t)."""
+        order = sorted(self.table.items(), key=lambda kv: (-kv[1], kv[0]))
+        batch, firsts, seconds = [], set(), set()
+        for key, c in order:
+            a, b = key >> 16, key & 0xFFFF
+            if c == 0 or a == b or b in firsts or a in seconds:
+                break
+            batch.append((a, b, c))
+            firsts.add(a)
+            seconds.add(b)
+            if len(batch) == limit:
+                break
+        return batch
+
+    def scan_batch(self, batch, n_merge):
+        """The stream pass for the first n_merge pairs of the batch (k_fused_batch / k_scan_batch): returns the new
+        shard and (m_j, ADJ, L, R) of THIS shard.  A match of j that directly follows a match of i counts in
+        ADJ[i][j] instead of L_j / R_i."""
+        t, n = self.toks, len(self.toks)
+        idm, endbit = self.idmask, self.endbit
+        l_t0, l_t1, _ = self.left
+        r_h0, r_h1 = self.right
+        index = {(a, b): j for j, (a, b, _) in enumerate(batch[:n_merge])}
+
+        def get(i):
+            if 0 <= i < n:
+                return t[i]
+            return {-1: l_t0, -2: l_t1, n: r_h0, n + 1: r_h1}[i]
+
+        def match_at(i):            # index of the batch pair that starts at position i (halo positions too), else None
+            s0, s1 = get(i), get(i + 1) if i + 1 <= n + 1 else HOLE
+            if s0 == HOLE or s1 == HOLE or (s0 & endbit):
+                return None
+            return index.get((s0, s1 & idm))
+        nb = len(batch)
+        m = [0] * nb
+        adj = {}
+        L, R = {}, {}
+        new = []
+        i = 0
+        # (a match whose first token is the left neighbour's last token is that rank's: skip its second token here)
+        if n and match_at(-1) is not None:
+            j = match_at(-1)
+            y = get(1)
+            if not (t[0] & endbit) and y != HOLE and match_at(1) is None:
+                R[(j, y & idm)] = R.get((j, y & idm), 0) + 1
+            i = 1
+        while i < n:
+            j = match_at(i)
+            if j is None:
+                new.append(t[i])
+                i += 1
+                continue
+            X = 256 + self.k + j
+            second = get(i + 1)
+            new.append(X | (second & endbit))
+            m[j] += 1
+            x = get(i - 1)
+            if x != HOLE and not (x & endbit):
+                p = match_at(i - 2)
+                if p is not None:                      # ... (a', b') (a, b): (b', a) -> (X', X)
+                    adj[(p, j)] = adj.get((p, j), 0) + 1
+                else:
+                    L[(j, x)] = L.get((j, x), 0) + 1
+            if i + 1 < n:                              # the second token is mine: its right neighbour
+                y = get(i + 2)
+                if not (second & endbit) and y != HOLE and match_at(i + 2) is None:
+                    R[(j, y & idm)] = R.get((j, y & idm), 0) + 1
+            i += 2
+        return new, m, adj, L, R
+
+    def sequence(self, limit):
+        if not self.table:
+            return 0
+        batch = self.select_batch(limit)
+        if len(batch) < 2:
+            return -1                                   # a (t,t), zero-count or lone pair: the caller takes the one-pair path
+        nb, ids, BM = len(batch), 256 + self.k, self.BATCH_MAX
+        pitch = self.lr_pitch(ids)
+        hdrb = BM + BM * BM
+        words = self.hdr + hdrb + 2 * nb * pitch        # exchange_words(c, ids, n_pairs) in train.cpp
+        _, m, adj, L, R = self.scan_batch(batch, nb)
+        xb = np.zeros(words, dtype=np.int64)
+        for j in range(nb):
+            xb[self.hdr + j] = m[j]
+        for (p, j), w in adj.items():
+            xb[self.hdr + BM + p * BM + j] = w
+        lr0 = self.hdr + hdrb
+        for (j, x), w in L.items():
+            xb[lr0 + (2 * j) * pitch + x] = w
+        for (j, y), w in R.items():
+            xb[lr0 + (2 * j + 1) * pitch + y] = w
+        xb = self.allreduce(xb)
+        assert len(xb) == words
+        self.exchanged.append((nb, ids, words))
+        gm = [int(xb[self.hdr + j]) for j in range(nb)]
+        ADJ = xb[self.hdr + BM:self.hdr + BM + BM * BM].reshape(BM, BM)
+        Lr = [xb[lr0 + (2 * j) * pitch:lr0 + (2 * j) * pitch + ids] for j in range(nb)]
+        Rr = [xb[lr0 + (2 * j + 1) * pitch:lr0 + (2 * j + 1) * pitch + ids] for j in range(nb)]
+        # ---- k_adj_sums / k_delta_max / k_adj_max / k_validate
+        adj_in = [int(ADJ[:nb, j].sum()) for j in range(nb)]
+        adj_out = [int(ADJ[j, :nb].sum()) for j in range(nb)]
+
+        def packed(c, key):
+            return (c, -key)
+        maxp = [None] * nb
+        for j in range(nb):
+            Xj = ids + j
+            best = None
+            for x in np.nonzero(Lr[j])[0]:
+                c = packed(int(Lr[j][x]) + adj_in[j], (int(x) << 16) | Xj)
+                best = c if best is None or c > best else best
+            for y in np.nonzero(Rr[j])[0]:
+                c = packed(int(Rr[j][y]) + adj_out[j], (Xj << 16) | int(y))
+                best = c if best is None or c > best else best
+            maxp[j] = best
+        for p in range(nb):
+            for q in range(nb):
+                w = int(ADJ[p, q])
+                if not w:
+                    continue
+                def raise_(j, v):
+                    if maxp[j] is None or v > maxp[j]:
+                        maxp[j] = v
+                raise_(max(p, q), packed(w, ((ids + p) << 16) | (ids + q)))
+                raise_(q, packed(adj_in[q], (batch[p][1] << 16) | (ids + q)))
+                raise_(p, packed(adj_out[p], ((ids + p) << 16) | batch[q][0]))
+        commit = nb
+        run = None
+        for j in range(nb):
+            key_j = (batch[j][0] << 16) | batch[j][1]
+            if j >= 1 and run is not None and packed(batch[j][2], key_j) <= run:
+                commit = j
+                break
+            if maxp[j] is not None and (run is None or maxp[j] > run):
+                run = maxp[j]
+        # a kept match that touches a dropped one keeps its plain neighbour
+        if commit < nb:
+            for r in range(nb):
+                for q in range(nb):
+                    w = int(ADJ[r, q])
+                    if not w:
+                        continue
+                    if r >= commit and q < commit:
+                        Lr[q][batch[r][1]] += w
+                    elif r < commit and q >= commit:
+                        Rr[r][batch[q][0]] += w
+        # ---- k_apply_batch
+        tab = self.table
+
+        def add(key, d):
+            tab[key] = tab.get(key, 0) + d
+            assert tab[key] >= 0, "negative count"
+        for j in range(commit):
+            a, b, c = batch[j]
+            X = ids + j
+            for x in np.nonzero(Lr[j])[0]:
+                w = int(Lr[j][x])
+                add((int(x) << 16) | a, -w)
+                add((int(x) << 16) | X, w)
+            for y in np.nonzero(Rr[j])[0]:
+                w = int(Rr[j][y])
+                add((b << 16) | int(y), -w)
+                add((X << 16) | int(y), w)
+            assert gm[j] == c, "an (a,b), a != b, pair is merged wherever it occurs"
+            add((a << 16) | b, -gm[j])
+        for p in range(commit):
+            for q in range(commit):
+                w = int(ADJ[p, q])
+                if w:
+                    add((batch[p][1] << 16) | batch[q][0], -w)
+                    add(((ids + p) << 16) | (ids + q), w)
+        # ---- the rewrite (the fused pass's output when the whole batch is kept, else k_rewrite_marked for the prefix)
+        self.toks = self.scan_batch(batch, commit)[0]
+        for j in range(commit):
+            self.merges.append((batch[j][0], batch[j][1]))
+            self.counts.append(batch[j][2])
+        self.k += commit
+        # ---- the edges of the rewritten shards (second, small all-reduce)
+        xe = np.zeros(self.hdr, dtype=np.int64)
+        base = 2 + 8 * self.rank
+        xe[base:base + 8] = self.edge()
+        xe = self.allreduce(xe)
+        self.compose([[int(v) for v in xe[2 + 8 * r:10 + 8 * r]] for r in range(self.world)])
+        return commit
+
+    def train_batched(self, vocab_size, limit=8):
+        """The product's loop: batch sequences, with the one-pair path (self.merge) for (t,t) and zero-count pairs."""
+        self.begin()
+        self.exchanged = []
+        target = vocab_size - 256
+        while self.k < target:
+            got = self.sequence(min(limit, target - self.k))
+            if got == 0:
+                break
+            if got > 0:
+                continue
+            a, b, c = self.argmax()
+            self.merges.append((a, b))
+            self.counts.append(c)
+            if c > 0:
+                self.merge(a, b, 256 + self.k)
+            self.k += 1
+        return self.merges, self.counts
+
     def train(self, vocab_size):
         self.begin()
         for i in range(256, vocab_size):

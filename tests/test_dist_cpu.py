@@ -1,7 +1,9 @@
 """CPU, world_size 2 and 3 over gloo: the sharded training protocol
 (tests/dist_model.py, the executable spec of the multi-GPU path) against the
 single-rank oracle.  Each rank holds one contiguous shard; the only
-communication is one sum all-reduce per merge (plus one at the start)."""
+communication is sum all-reduces: one at the start, then one per merge
+(per_merge) or two per batch sequence (batch_sequences: the count deltas of
+all the batch's pairs, then the shard edges) -- the exchange the product runs."""
 import os
 import socket
 import sys
@@ -38,7 +40,7 @@ def _cases():
     return cases
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, batched=False):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "minbpe-cc_amd", "python"))
     sys.path.insert(0, HERE)
@@ -71,7 +73,15 @@ def _worker(rank, world, port, q):
                 sel = off[(off >= lo) & (off <= hi)]
                 loff = (sel - lo).astype(np.int64)
             sh = Shard(data[lo:hi], loff, rank, world, allreduce)
-            merges, counts = sh.train(vocab)
+            if batched:
+                merges, counts = sh.train_batched(vocab, limit=8)
+                # what crossed the wire per sequence: header + batch header + exactly the LR rows of the batch's pairs
+                for nb, ids, words in sh.exchanged:
+                    assert words == sh.hdr + (sh.BATCH_MAX + sh.BATCH_MAX ** 2) + 2 * nb * ((ids + 63) & ~63)
+                if ci in (0, 11, 12):       # (random bytes, text: the tiny-alphabet cases have nothing independent to batch)
+                    assert sum(nb >= 2 for nb, _, _ in sh.exchanged) >= 3, "case %d ran no batches" % ci
+            else:
+                merges, counts = sh.train(vocab)
             want_m, want_c = O.train(data, vocab, off)
             assert [list(m) for m in merges] == want_m.tolist(), "case %d merges" % ci
             assert list(counts) == want_c.tolist(), "case %d counts" % ci
@@ -100,13 +110,17 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("batched", [False, True], ids=["per_merge", "batch_sequences"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_protocol_over_gloo(world):
+def test_sharded_protocol_over_gloo(world, batched):
+    """per_merge: one all-reduce of (m, adj, L, R) per merge.  batch_sequences: what the product runs -- several
+    independent pairs per stream pass, one all-reduce of [header][m_j, ADJ][L_j, R_j rows] per sequence, validation of
+    the batch against the one-at-a-time order, a second small all-reduce for the shard edges."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, batched)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]

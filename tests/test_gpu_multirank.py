@@ -38,10 +38,15 @@ def _both_batch_paths(request):
     FUSED_MIN = 24
 
 
+EXCHANGES = []        # (u32 words, merges committed before) of every exchange of the run in progress
+HDRB = (1024 + 1024 * 1024 + 3) // 4 * 4     # batch header of the exchange buffer: m_j, ADJ (kBatchMax = 1024)
+
+
 def _allreduce(trainers):
     bufs = [t.exchange_buffer() for t in trainers]
     n = bufs[0][1]
     assert all(b[1] == n for b in bufs)
+    EXCHANGES.append((n, trainers[0].stats()["n_merges"]))
     total = np.zeros(n, dtype=np.uint32)
     tmp = np.zeros(n, dtype=np.uint32)
     for ptr, _ in bufs:
@@ -73,6 +78,7 @@ def _train_sharded(data, cuts, vocab, chunk_off=None, decode_check=False):
         assert all(c == mbpe.NEED_EXCHANGE for c in codes)
         _allreduce(trainers)
         assert all(t.exchange_done() == mbpe.OK for t in trainers)
+        del EXCHANGES[:]
         codes = [t.train_steps(vocab - 256) for t in trainers]
         while codes[0] == mbpe.NEED_EXCHANGE:
             assert all(c == mbpe.NEED_EXCHANGE for c in codes)
@@ -80,6 +86,19 @@ def _train_sharded(data, cuts, vocab, chunk_off=None, decode_check=False):
             codes = [t.exchange_done() for t in trainers]
         assert all(c == mbpe.OK for c in codes)
         results = [t.train_result() for t in trainers]
+        # What crossed the "wire": a sequence exchanges its count deltas -- both headers + exactly the rows L_j, R_j
+        # (lr_pitch(ids) cells each) of the pairs of its batch, not the whole 2 x 1024 x ids block -- and then the
+        # shard edges (the small header alone).
+        hdr = (2 + 8 * R + 3) // 4 * 4
+        n_final = len(results[0][0])
+        deltas = [(n, k) for n, k in EXCHANGES if n != hdr]
+        for i, (n, k) in enumerate(deltas):
+            pitch = (256 + k + 63) & ~63
+            rows, rest = divmod(n - hdr - HDRB, 2 * pitch)
+            committed = (deltas[i + 1][1] if i + 1 < len(deltas) else n_final) - k
+            assert rest == 0 and 1 <= rows <= 1024, (n, k)
+            assert committed <= rows, "a sequence exchanged %d pairs' rows and committed %d merges" % (rows, committed)
+
         streams = [t.stream()[0] for t in trainers]
         tables = [t.pairs_dict() for t in trainers]
         if decode_check:
