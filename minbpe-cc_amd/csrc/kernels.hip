@@ -94,7 +94,7 @@ __device__ __forceinline__ uint32_t wave_sum_le8(uint32_t v, unsigned long long 
 //   L_j[x] = LR[lr_idx(pitch, x, j, 0)],  R_j[y] = LR[lr_idx(pitch, y, j, 1)]
 // (largest index: 2048 rows of 65,536 cells = 2^27)
 __device__ __forceinline__ uint32_t lr_idx(uint32_t pitch, uint32_t x, uint32_t j, uint32_t side) {
-    return (2u * j + side) * pitch + x;
+    return __umul24(2u * j + side, pitch) + x;          // (row < 2048, pitch <= 65,536: one v_mad_u32_u24)
 }
 
 // Count deltas of frequent neighbours.  In text a pair such as ("e", " ") has millions of
@@ -1739,6 +1739,13 @@ struct BatchLut {
 __device__ __forceinline__ uint32_t pair_hash(uint32_t mul, uint32_t first, uint32_t second) {
     return (__umul24(second, mul) + first) & (kBuckets - 1u);      // one v_mad_u32_u24
 }
+// the same with the batch's (wave-uniform) multiplier in a scalar register: inline asm, because the compiler would
+// make the multiply-add a 64-bit v_mad_u64_u32
+__device__ __forceinline__ uint32_t pair_hash_u(uint32_t uniform_mul, uint32_t first, uint32_t second) {
+    uint32_t h;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(uniform_mul), "v"(first));
+    return h & (kBuckets - 1u);
+}
 
 // The (t,t) members of the batch, for the kernel instantiations that handle them: token -> stand-in id
 // (direct-mapped on the token's low bits; k_sel_pick keeps the slots distinct), stand-in -> token and
@@ -1803,7 +1810,7 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
 // is (first, second) a batch pair?  first may be any raw slot value (a hole or a
 // token with the chunk-end bit never matches), second the id of the next live token
 __device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, uint32_t second) {
-    const auto bk = lut.m->bucket[pair_hash(lut.mul, first, second)];
+    const auto bk = lut.m->bucket[pair_hash_u(lut.mul, first, second)];
     const uint32_t kk = first | (second << 16);
 #if MBPE_LUT_KEYS == 2
     return bk.x == kk || bk.y == kk;
@@ -1846,7 +1853,7 @@ __device__ __forceinline__ bool pair_hit(const BatchLut &lut, uint32_t first, ui
 
 // index of the pair (only called for pairs that passed pair_test)
 __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, uint32_t second) {
-    const uint32_t h = pair_hash(lut.mul, first, second);
+    const uint32_t h = pair_hash_u(lut.mul, first, second);
 #if MBPE_LUT_KEYS == 2
     const uint32_t ix = lut.m->bidx[h];
 #endif
@@ -2714,10 +2721,17 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
-                                                 DeltaCache &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum) {
+                                                 DeltaCache &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
+                                                 __amdgpu_buffer_rsrc_t lr_rsrc) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     const uint32_t pitch = lr_pitch(X0);        // uniform
+    // (plain instantiation: the delta atomics go through a buffer resource -- scalar base, 32-bit lane offset -- so
+    //  that no 64-bit address is built per match; the LR block is below 4 GB)
+    auto delta_add = [&](uint32_t idx, uint32_t delta) {
+        if (dc_on) dc_add(dc, true, LR, idx, delta);
+        else __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)delta, lr_rsrc, idx << 2, 0, 0);
+    };
     // (an opaque copy of the lane id: the 64-bit lane masks below are cheaper to rebuild per tile than
     //  to keep in registers across the streaming loop, where the compiler would spill them)
     uint32_t lane = lane_id();
@@ -2794,9 +2808,9 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
             if (counted && DIAG != 2) {
                 if (is_a && ((touch >> j) & 1u)) {        // ... (a', b') (a, b): (b', a) -> (X', X)
                     atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
-                    dc_add(dc, dc_on, LR, lr_idx(pitch, self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b')
+                    delta_add(lr_idx(pitch, self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b')
                 } else {
-                    dc_add(dc, dc_on, LR, lr_idx(pitch, nb & idmask, ja, is_a ? 0u : 1u), 1u);
+                    delta_add(lr_idx(pitch, nb & idmask, ja, is_a ? 0u : 1u), 1u);
                 }
             }
             pjb = is_a ? pjb : pj;
@@ -2882,6 +2896,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     auto clamp_tile = [&](uint64_t t) { return (uint32_t)(t < n_tiles ? t : last_tile); };
     const __amdgpu_buffer_rsrc_t sums_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(LR, 0, 0xFFFFFFFCu, 0x00020000);
     TileIn t0 = tile_issue(tok, sums_rsrc, tile);
     TileIn t1 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + n_waves));
     bool v1 = (uint64_t)tile + n_waves < n_tiles;
@@ -2948,7 +2963,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             } else if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
                 outq = fused_tile_full<MODE, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
-                                                wave_rm, wrote_sum);
+                                                wave_rm, wrote_sum, lr_rsrc);
             }
         }
         // every tile's summary goes to the side array (an unchanged tile's as it was): no tile marks needed
