@@ -37,7 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "minbpe-cc_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 GOLDEN = 0x9E3779B97F4A7C15
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def _s64(v):
@@ -413,12 +413,18 @@ def main():
     # ---- pair-count scan (the north star's graded kernel), timed last: an idle chip needs ~25 launches of this
     # kernel (some tens of milliseconds of work) to reach its sustained clock -- launch times fall by a fifth
     # meanwhile -- and by now the process has kept it busy for a while.  5 launches of warm-up, then the MEAN of
-    # 30 launches; every launch time is in the record.
+    # 30 launches (three groups of ten, back to back inside one pair of HIP events each: a marker per launch adds
+    # 20-45 us to a 1 ms kernel, which rocprofv3's per-dispatch durations do not contain).
     scan_ms = []
-    for _ in range(35):
+    for _ in range(5):
         tr.pair_count_u8(want_table=False)
         scan_ms.append(tr.stats()["ms_pair_count"])
-    scan_ms_avg = sum(scan_ms[5:]) / 30.0
+    tr.set_option("pc_repeat", 10)           # 3 x 10 launches back to back: one pair of HIP events around each ten
+    for _ in range(3):
+        tr.pair_count_u8(want_table=False)
+        scan_ms.append(tr.stats()["ms_pair_count"])
+    tr.set_option("pc_repeat", 1)
+    scan_ms_avg = sum(scan_ms[5:]) / 3.0
     scan_gbs = (hi - lo) / (scan_ms_avg * 1e-3) / 1e9
 
     if rank == 0:
@@ -491,9 +497,11 @@ def main():
                 "traffic": pmc_traffic("k_pair_count_u8", args.config, total_bytes, vocab, world),
                 "algorithmic_bytes_per_launch": hi - lo,
                 "avg_launch_ms": scan_ms_avg,
-                "avg_launch_ms_is": "mean of launches 6-35 of 35, taken after the training runs of this process (chip at "
-                                    "its sustained clock); mean over all 35: %.4f" % (sum(scan_ms) / len(scan_ms)),
+                "avg_launch_ms_is": "mean of launches 6-35 of 35 (three groups of ten launches back to back, HIP events "
+                                    "around each group), after 5 warm-up launches, taken after the training runs of this "
+                                    "process (chip at its sustained clock)",
                 "launch_ms_all": [round(x, 4) for x in scan_ms],
+                "launch_ms_all_is": "5 single launches (warm-up), then the mean launch time of each group of ten",
             },
             "begin_ms": begin_stats["ms_begin"],
             "full_run": full_run,

@@ -250,6 +250,8 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *                   (default), 0 = always walk the argmax bounds pair by pair
  *   "sel_cap"       capacity of the candidate list of the threshold selection (default and
  *                   limit 4096, at least 64; tests lower it to force the overflow path)
+ *   "pc_repeat"     mbpe_pair_count_u8 called without an output table launches the scan this many times
+ *                   back to back and reports the mean duration in mbpe_stats.ms_pair_count (timing only)
  *   "hier_argmax"   -1 auto / 0 scan every entry / 1 walk the block bounds
  *                   (single-merge mode)
  *   "force_exchange" 1 = take the multi-rank path (rank edges, exchange) even

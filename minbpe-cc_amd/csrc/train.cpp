@@ -211,6 +211,7 @@ struct mbpe_ctx {
     int64_t opt_first_batches = 0;  // `first` mode: 1 = pairs whose counts no other pair shares are merged in batches too
                                     //   (no faster on text: words make chains of pairs with one count)
     int64_t opt_first = 0;          // 1: `first` tie-break (insertion order, PairCount.h:65-74) instead of lexical
+    int64_t opt_pc_repeat = 1;      // mbpe_pair_count_u8 without an output table: launches per call (timing)
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
     // multi-GPU: what the selection of the sequence in flight decided (k_done, k_limit, batch_n, commit_n of DevCtl),
     // read back while its stream pass runs, so that exactly the cells the batch can touch are exchanged
@@ -514,6 +515,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "chunk_barrier") c->opt_barrier = value < 0 ? -1 : value != 0;       // (read by the next mbpe_train_begin)
     else if (n == "first_batches") c->opt_first_batches = value != 0;
     else if (n == "sel_cap") c->opt_sel_cap = std::min<int64_t>(std::max<int64_t>(64, value), kSelCap);
+    else if (n == "pc_repeat") c->opt_pc_repeat = std::min<int64_t>(std::max<int64_t>(1, value), 1000);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
 }
@@ -670,15 +672,21 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
     if (!c->pc_bp) HIPCHK(hipMalloc(&c->pc_bp, 65536 * 4));
     uint32_t *bp = c->pc_bp;
     HIPCHK(hipMemsetAsync(bp, 0, 65536 * 4, c->stream));
+    // ("pc_repeat" > 1: that many launches back to back between the two events -- the kernel's sustained duration
+    //  without one event marker's overhead per launch; the table then holds that multiple of every count)
+    const int reps = table65536_out ? 1 : (int)std::max<int64_t>(1, c->opt_pc_repeat);
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    if (!c->inert) launch_pair_count_u8(c->stream, c->d_text, c->n_bytes, c->d_endmask, bp, c->n_cus, c->pc_scratch);
+    if (!c->inert)
+        for (int r = 0; r < reps; ++r)
+            launch_pair_count_u8(c->stream, c->d_text, c->n_bytes, c->d_endmask, bp, c->n_cus, c->pc_scratch);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && table65536_out) e = hipMemcpy(table65536_out, bp, 65536 * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { mbpe_host::set_last_error(hip_err("pair count", e)); return MBPE_ERR_HIP; }
     HIPCHK(hipEventElapsedTime(&c->stats.ms_pair_count, c->ev0, c->ev1));
-    c->stats.pair_count_launches++;
+    c->stats.ms_pair_count /= (float)reps;
+    c->stats.pair_count_launches += (uint32_t)reps;
     return MBPE_OK;
 }
 

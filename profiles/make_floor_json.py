@@ -1,21 +1,21 @@
 """profiles/r03_fused_floor.json, read by bench.py's floor_model: the two floors of a fused pass from measurements.
 
-  python3 profiles/make_floor_json.py --diag-log gpurun_out/r03/fused_diag.log --sq profiles/r03_pmc_sq.csv \
-          --kernel-ms 8.41 > profiles/r03_fused_floor.json
+  python3 profiles/make_floor_json.py --diag-log gpurun_out/r03/fused_diag.log \
+          --counters <counter_collection.csv> --trace <kernel_trace.csv> > profiles/r03_fused_floor.json
 
   --diag-log   output of tools/fused_diag.py (a -DMBPE_DIAG build): the line "diag 4 ..." is the copy-only build of
                k_fused_batch (load tile + summaries, store tile) on 4.29e9 slots = 17.18 GB
-  --sq         summarize.py sq output holding SQ_INSTS_VALU and SQ_BUSY_CYCLES of k_fused_batch (maxima = the
-               full-size passes: 8,388,608 tiles)
-  --kernel-ms  duration of such a full-size pass in the same profiled run (for the shader clock:
-               SQ_BUSY_CYCLES is summed over the 32 shader engines)
+  --counters / --trace   rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU ... --kernel-trace of ONE bench.py run: the
+               k_fused_batch dispatch with the most vector instructions (a full-size pass: 8,388,608 tiles) gives the
+               instructions per tile and, with its own duration, the shader clock (SQ_BUSY_CYCLES is summed over the
+               32 shader engines)
 """
-import argparse, csv, json, re
+import argparse, collections, csv, json, re
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--diag-log", required=True)
-ap.add_argument("--sq", required=True)
-ap.add_argument("--kernel-ms", type=float, required=True)
+ap.add_argument("--counters", required=True)
+ap.add_argument("--trace", required=True)
 ap.add_argument("--slots", type=float, default=4294967296.0)
 a = ap.parse_args()
 copy_ms = None
@@ -23,19 +23,26 @@ for line in open(a.diag_log):
     m = re.match(r"diag 4 .*avg ms ([0-9.]+)", line)
     if m:
         copy_ms = float(m.group(1))
-valu = busy = None
-for r in csv.DictReader(open(a.sq)):
-    if r["kernel"] == "k_fused_batch" and r["counter"] == "SQ_INSTS_VALU":
-        valu = float(r["max"])
-    if r["kernel"] == "k_fused_batch" and r["counter"] == "SQ_BUSY_CYCLES":
-        busy = float(r["max"])
+by = collections.defaultdict(dict)
+for r in csv.DictReader(open(a.counters)):
+    if "k_fused_batch" in r["Kernel_Name"]:
+        by[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+did, c = max(by.items(), key=lambda kv: kv[1].get("SQ_INSTS_VALU", 0.0))
+dur_ms = None
+for r in csv.DictReader(open(a.trace)):
+    if r["Dispatch_Id"] == did:
+        dur_ms = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6
 tiles = a.slots / 512.0
+clock = c["SQ_BUSY_CYCLES"] / 32.0 / (dur_ms * 1e-3) / 1e9
 print(json.dumps({
     "copy_only_GBps": 4.0 * a.slots / (copy_ms * 1e-3) / 1e9,
     "copy_only_ms": copy_ms,
-    "valu_per_tile": valu / tiles,
-    "valu_per_launch": valu,
-    "clock_GHz": busy / 32.0 / (a.kernel_ms * 1e-3) / 1e9,
+    "valu_per_tile": c["SQ_INSTS_VALU"] / tiles,
+    "valu_per_launch": c["SQ_INSTS_VALU"],
+    "salu_per_launch": c.get("SQ_INSTS_SALU"),
+    "profiled_launch_ms": dur_ms,
+    "clock_GHz": clock,
+    "valu_busy_frac": c["SQ_INSTS_VALU"] * 4.0 / (c["SQ_BUSY_CYCLES"] / 32.0 * 1024.0),
     "simds": 1024,
-    "sources": "tools/fused_diag.py (MBPE_FUSED_DIAG=4) + rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES, collected by profiles/collect_r03.sh",
+    "sources": "tools/fused_diag.py (MBPE_FUSED_DIAG=4) + rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace of one bench.py run, collected by profiles/collect_r03.sh",
 }, indent=1))

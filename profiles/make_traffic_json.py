@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_traffic.json from the condensed FETCH_SIZE / WRITE_SIZE passes (collect_r02.sh):
+"""profiles/rNN_pmc_traffic.json from the condensed FETCH_SIZE / WRITE_SIZE passes (collect_rNN.sh; usage: make_traffic_json.py <dir> [r03]):
 HBM bytes per working launch of every kernel, read by bench.py for `roofline.traffic`."""
 import csv
 import json
@@ -7,6 +7,7 @@ import os
 import sys
 
 d = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 out = {
     "workload": {"config": "synthetic", "corpus_bytes": 4 << 30, "vocab_size": 32000, "n_gpus": 1,
                  "command": "bench.py --steps 20 --warmup 5 --no-full-run --no-cpu-baseline (sequences 0..25: 4.29e9 "
@@ -15,7 +16,7 @@ out = {
               "(gfx950 wide-read correction, /opt/skills/guides/MI355X_MICROARCH.md, HBM)",
 }
 for counter, key in (("FETCH_SIZE", "fetch_bytes"), ("WRITE_SIZE", "write_bytes")):
-    path = os.path.join(d, "r02_pmc_%s.csv" % counter)
+    path = os.path.join(d, "%s_pmc_%s.csv" % (tag, counter))
     for r in csv.DictReader(open(path)):
         k = r["kernel"].split("<")[0]
         out.setdefault(k, {})[key] = float(r["avg_bytes_corrected"])
