@@ -1702,20 +1702,30 @@ __global__ void k_apply(PairTable t, DevCtl *ctl, const unsigned long long *__re
 #ifndef MBPE_LUT_KEYS
 #define MBPE_LUT_KEYS 2
 #endif
-constexpr uint32_t kBucketKeys = MBPE_LUT_KEYS;          // keys per bucket: 2 (8-byte read) or 4 (16-byte read)
+constexpr uint32_t kBucketKeys = MBPE_LUT_KEYS;          // keys per bucket: 2 (one 8-byte read), 3 (8 + 4 bytes) or 4 (16 bytes)
 #ifndef MBPE_LUT_BUCKETS
-#define MBPE_LUT_BUCKETS (16384 / MBPE_LUT_KEYS)     /* 8192 buckets of two keys: 64 KB + 32 KB of indices */
+#define MBPE_LUT_BUCKETS (MBPE_LUT_KEYS == 4 ? 4096 : 8192)
 #endif
 constexpr uint32_t kBuckets = MBPE_LUT_BUCKETS;
 static_assert((kBuckets & (kBuckets - 1u)) == 0, "the hash is masked");
 constexpr uint32_t kEmptyPair = 0xFFFEFFFEu;
-static_assert(kBucketKeys == 2 || kBucketKeys == 4, "bucket = one 8- or 16-byte LDS read");
+static_assert(kBucketKeys >= 2 && kBucketKeys <= 4, "bucket = an 8-byte, an 8- and a 4-byte, or a 16-byte LDS read");
 
 static_assert(kBatchMax <= 65536, "batch indices are stored in 16 bits");
+// 8192 buckets of two keys.  A batch ends when some bucket would need a third key under every hash multiplier still in
+// the race (expected overflowing buckets n^3 / (6 B^2): near 1,400 pairs with eight multipliers).  MBPE_LUT_KEYS 3 (a
+// second, 4-byte read per test: 144 KB of LDS, batches of 2,048 pairs with -DMBPE_BATCH_MAX=2048) was built and measured
+// in round 3: the fused pass went from 8.3 to 10.5 ms at the same batch size -- every LDS read in the per-slot path costs
+// as much as eight vector instructions -- which the 7 passes it saved (83 -> 76) do not pay back.
 struct BatchLutMem {             // (in LDS, one per workgroup)
 #if MBPE_LUT_KEYS == 2
     uint2 bucket[kBuckets];
     uint32_t bidx[kBuckets];     // batch index of bucket.x (low half) and bucket.y (high half)
+#elif MBPE_LUT_KEYS == 3
+    uint2 bucket[kBuckets];      // keys 0 and 1
+    uint32_t bucket2[kBuckets];  // key 2
+    uint32_t bidx[kBuckets];     // batch index of bucket.x (low half) and bucket.y (high half)
+    uint16_t bidx2[kBuckets];    // ... of bucket2
 #else
     uint4 bucket[kBuckets];
     uint2 bidx[kBuckets];        // batch indices of bucket.x .. bucket.w, 16 bits each
@@ -1784,9 +1794,13 @@ __device__ __forceinline__ void tt_flush(TTInfo &ti, uint32_t *hdr_m) {
 
 __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys, uint32_t fake) {
     uint32_t *words = reinterpret_cast<uint32_t *>(lut.m->bucket);
-    for (uint32_t i = threadIdx.x; i < kBuckets * kBucketKeys; i += blockDim.x) words[i] = kEmptyPair;
+    constexpr uint32_t kMainKeys = kBucketKeys == 3 ? 2u : kBucketKeys;      // keys per bucket in `bucket`
+    for (uint32_t i = threadIdx.x; i < kBuckets * kMainKeys; i += blockDim.x) words[i] = kEmptyPair;
     uint32_t *iw = reinterpret_cast<uint32_t *>(lut.m->bidx);
-    for (uint32_t i = threadIdx.x; i < kBuckets * kBucketKeys / 2; i += blockDim.x) iw[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kBuckets * kMainKeys / 2; i += blockDim.x) iw[i] = 0;
+#if MBPE_LUT_KEYS == 3
+    for (uint32_t i = threadIdx.x; i < kBuckets; i += blockDim.x) { lut.m->bucket2[i] = kEmptyPair; lut.m->bidx2[i] = 0; }
+#endif
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t n_tt = 0;
@@ -1798,8 +1812,15 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
             const uint32_t h = pair_hash(lut.mul, a, b);
             const uint32_t kk = a | (b << 16);
             uint32_t r = 0;                       // first free key of the bucket (selection keeps it within kBucketKeys)
-            while (r + 1 < kBucketKeys && words[h * kBucketKeys + r] != kEmptyPair) ++r;
-            words[h * kBucketKeys + r] = kk;
+            while (r + 1 < kMainKeys && words[h * kMainKeys + r] != kEmptyPair) ++r;
+#if MBPE_LUT_KEYS == 3
+            if (words[h * kMainKeys + r] != kEmptyPair) {      // both taken: the bucket's third key
+                lut.m->bucket2[h] = kk;
+                lut.m->bidx2[h] = (uint16_t)j;
+                continue;
+            }
+#endif
+            words[h * kMainKeys + r] = kk;
             uint16_t *ix = reinterpret_cast<uint16_t *>(&lut.m->bidx[h]);
             ix[r] = (uint16_t)j;
         }
@@ -1810,10 +1831,13 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
 // is (first, second) a batch pair?  first may be any raw slot value (a hole or a
 // token with the chunk-end bit never matches), second the id of the next live token
 __device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, uint32_t second) {
-    const auto bk = lut.m->bucket[pair_hash_u(lut.mul, first, second)];
+    const uint32_t hh = pair_hash_u(lut.mul, first, second);
+    const auto bk = lut.m->bucket[hh];
     const uint32_t kk = first | (second << 16);
 #if MBPE_LUT_KEYS == 2
     return bk.x == kk || bk.y == kk;
+#elif MBPE_LUT_KEYS == 3
+    return bk.x == kk || bk.y == kk || lut.m->bucket2[hh] == kk;
 #else
     return bk.x == kk || bk.y == kk || bk.z == kk || bk.w == kk;
 #endif
@@ -1829,6 +1853,10 @@ __device__ __forceinline__ uint32_t pair_miss(const BatchLut &lut, uint32_t firs
     const uint32_t kk = first | (second << 16);
     const uint32_t dx = bk.x ^ kk, dy = bk.y ^ kk;
     uint32_t d = dx < dy ? dx : dy;
+#if MBPE_LUT_KEYS == 3
+    const uint32_t dz = lut.m->bucket2[h & (kBuckets - 1u)] ^ kk;
+    d = d < dz ? d : dz;
+#endif
 #if MBPE_LUT_KEYS == 4
     const uint32_t dz = bk.z ^ kk, dw = bk.w ^ kk;
     const uint32_t e = dz < dw ? dz : dw;
@@ -1846,25 +1874,59 @@ __device__ __forceinline__ bool pair_hit(const BatchLut &lut, uint32_t first, ui
     const uint32_t kk = first | (second << 16);
 #if MBPE_LUT_KEYS == 2
     return bk.x == kk || bk.y == kk;
+#elif MBPE_LUT_KEYS == 3
+    return bk.x == kk || bk.y == kk || lut.m->bucket2[h & (kBuckets - 1u)] == kk;
 #else
     return bk.x == kk || bk.y == kk || bk.z == kk || bk.w == kk;
+#endif
+}
+
+// ... and which of the bucket's keys matched (two-key buckets): the pair index is then ONE more LDS read (the bucket's
+// index word) instead of two -- an LDS read in the per-slot path costs as much as eight vector instructions.
+__device__ __forceinline__ bool pair_hit2(const BatchLut &lut, uint32_t first, uint32_t second, bool &second_key) {
+    uint32_t h;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(lut.mul), "v"(first));
+    const auto bk = lut.m->bucket[h & (kBuckets - 1u)];
+    const uint32_t kk = first | (second << 16);
+    second_key = bk.y == kk;
+#if MBPE_LUT_KEYS == 2
+    return bk.x == kk || second_key;
+#elif MBPE_LUT_KEYS == 3
+    return bk.x == kk || second_key || lut.m->bucket2[h & (kBuckets - 1u)] == kk;
+#else
+    return bk.x == kk || second_key || bk.z == kk || bk.w == kk;
 #endif
 }
 
 // index of the pair (only called for pairs that passed pair_test)
 __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, uint32_t second) {
     const uint32_t h = pair_hash_u(lut.mul, first, second);
-#if MBPE_LUT_KEYS == 2
-    const uint32_t ix = lut.m->bidx[h];
-#endif
     const uint32_t kk = first | (second << 16);
 #if MBPE_LUT_KEYS == 2
+    const uint32_t ix = lut.m->bidx[h];
     return (int)(lut.m->bucket[h].x == kk ? ix & 0xFFFFu : ix >> 16);
+#elif MBPE_LUT_KEYS == 3
+    // (a pair that is in the table and is neither of the first two keys of its bucket is the third)
+    const uint32_t ix = lut.m->bidx[h];
+    const uint32_t i3 = lut.m->bidx2[h];
+    const uint2 bk = lut.m->bucket[h];
+    return (int)(bk.x == kk ? ix & 0xFFFFu : bk.y == kk ? ix >> 16 : i3);
 #else
     const uint4 bk = lut.m->bucket[h];
     const uint2 i2 = lut.m->bidx[h];
     const uint32_t w = (bk.x == kk || bk.y == kk) ? i2.x : i2.y;
     return (int)((bk.x == kk || bk.z == kk) ? w & 0xFFFFu : w >> 16);
+#endif
+}
+
+// the same when the membership test has already told which key of the bucket matched (pair_hit2)
+__device__ __forceinline__ uint32_t lut_index_known(const BatchLut &lut, uint32_t first, uint32_t second, bool second_key) {
+#if MBPE_LUT_KEYS == 2
+    const uint32_t ix = lut.m->bidx[pair_hash_u(lut.mul, first, second)];
+    return second_key ? ix >> 16 : ix & 0xFFFFu;
+#else
+    (void)second_key;
+    return (uint32_t)lut_index(lut, first, second);
 #endif
 }
 
@@ -2123,7 +2185,8 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
     // and how many keys every bucket of the kernels' lookup table holds -- under each of the kHashSeeds hash
     // multipliers still in the race (small packed counters)
     __shared__ uint32_t set_first[2048], set_second[2048];
-    __shared__ uint8_t cnt_first[32768], cnt_second[32768];
+    constexpr uint32_t kCntFold = kSelCap > 4096u ? 0x1FFFu : 0x7FFFu;      // (a longer candidate list needs the LDS)
+    __shared__ uint8_t cnt_first[kCntFold + 1u], cnt_second[kCntFold + 1u];
     constexpr uint32_t kFillBits = kBucketKeys <= 3 ? 2 : 4, kFillPerWord = 32 / kFillBits;
     __shared__ uint32_t bucket_fill[kHashSeeds][kBuckets / kFillPerWord];
     __shared__ uint16_t acc_ci[kBatchMax];         // list position of every accepted member (written out after the walk)
@@ -2159,7 +2222,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         si[i] = i < n_l ? sel->eidx[i] : 0u;
     }
     for (uint32_t i = tid; i < 2048u; i += kPickThreads) { set_first[i] = 0; set_second[i] = 0; }
-    for (uint32_t i = tid; i < 32768u / 4u; i += kPickThreads) {
+    for (uint32_t i = tid; i < (kCntFold + 1u) / 4u; i += kPickThreads) {
         reinterpret_cast<uint32_t *>(cnt_first)[i] = 0;
         reinterpret_cast<uint32_t *>(cnt_second)[i] = 0;
     }
@@ -2277,7 +2340,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                     }
                     ++n_skip;
                     // (it loses occurrences to every member it depends on: red_q16 is the fraction per such member)
-                    const uint32_t n_dep = (uint32_t)cnt_first[b & 0x7FFFu] + cnt_second[a & 0x7FFFu];
+                    const uint32_t n_dep = (uint32_t)cnt_first[b & kCntFold] + cnt_second[a & kCntFold];
                     unsigned long long lose = (unsigned long long)n_dep * red_q16;
                     if (lose > 65536ull) lose = 65536ull;
                     const unsigned long long keep = (unsigned long long)count - (((unsigned long long)count * lose) >> 16);
@@ -2294,8 +2357,8 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             if (l0) {
                 set_first[a >> 5] |= 1u << (a & 31u);
                 set_second[b >> 5] |= 1u << (b & 31u);
-                if (cnt_first[a & 0x7FFFu] != 0xFFu) cnt_first[a & 0x7FFFu] += 1;
-                if (cnt_second[b & 0x7FFFu] != 0xFFu) cnt_second[b & 0x7FFFu] += 1;
+                if (cnt_first[a & kCntFold] != 0xFFu) cnt_first[a & kCntFold] += 1;
+                if (cnt_second[b & kCntFold] != 0xFFu) cnt_second[b & kCntFold] += 1;
                 acc_ci[accepted] = (uint16_t)ci;
                 if (tt && n_tt == 0) { bs->tt_index = accepted; bs->tt_token = a; }
             }
@@ -2717,7 +2780,8 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
 template <int MODE, int DIAG = 0>
 __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on, TTInfo &ti,
                                                  const uint32_t s[8], const uint32_t cj[8],
-                                                 uint32_t Am, unsigned long long m_live, uint32_t c_init, const Halo h,
+                                                 uint32_t Am, uint32_t Wm, bool tcin, bool tbin, unsigned long long m_live,
+                                                 uint32_t c_init, const Halo h,
                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
@@ -2746,14 +2810,12 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
     // carry "the last live token before this lane starts a match" over empty lanes
     const bool lastA = Am > (Lm & ~Am);
     const unsigned long long G = __ballot(lastA);
-    const bool tcin = pair_test(lut, h.p1, tile_first & idmask);          // uniform
     const unsigned long long CIN = (((G << 1) | (tcin ? 1ull : 0ull)) + E) & m_live;
     const uint32_t cin = lane_of(CIN) ? 1u : 0u;
     const uint32_t Bm = (((Am << 1) | cin) + Hm) & Lm;
     // the same for "the last live token before this lane ends a match"
     const bool lastB = Bm > (Lm & ~Bm);
     const unsigned long long GB = __ballot(lastB);
-    const bool tbin = h.p2 != kHole && pair_test(lut, h.p2, h.p1 & idmask);   // uniform
     const unsigned long long BIN = (((GB << 1) | (tbin ? 1ull : 0ull)) + E) & m_live;
     const uint32_t bin = lane_of(BIN) ? 1u : 0u;
     const uint32_t touch = Am & ((((Bm << 1) | bin) + Hm) & Lm);     // starts a match right after another one
@@ -2766,7 +2828,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
 #pragma unroll
     for (int j = 0; j < 8; ++j) ll = s[j] != kHole ? s[j] : ll;
     uint32_t lastj = 0;
-    if (lastA) lastj = (uint32_t)lut_index(lut, ll, c_init & idmask);
+    if (lastA) lastj = lut_index_known(lut, ll, c_init & idmask, ((Wm >> (31u - (uint32_t)__builtin_clz(Lm | 1u))) & 1u) != 0u);
     uint32_t p1, pj;
     const uint32_t pj_tile = tcin ? (uint32_t)lut_index(lut, h.p1, tile_first & idmask) : 0u;     // uniform
     if (m_live == ~0ull) {                   // the previous lane is the previous live lane
@@ -2797,7 +2859,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
             const bool is_a = (Am >> j) & 1u;
             uint32_t ja = pj;
             if (is_a) {
-                ja = (uint32_t)lut_index(lut, self, cj[j] & idmask);
+                ja = lut_index_known(lut, self, cj[j] & idmask, ((Wm >> j) & 1u) != 0u);
                 if (tt_on && (cj[j] & idmask) >= idmask - (uint32_t)kTTMax)      // a match of a (t,t) member: count it
                     atomicAdd(&ti.cnt[idmask - 1u - (cj[j] & idmask)], 1u);
             }
@@ -2826,7 +2888,11 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
             if (out[j] != kHole && (out[j] & idmask) >= idmask - (uint32_t)kTTMax)
                 out[j] = ti.tok[idmask - 1u - (out[j] & idmask)] | (out[j] & endbit);
     }
-    const uint32_t removed = rfl(wave_sum(__popc(Bm)));
+    // (sum over the lanes of the set bits of an 8-bit mask with ballots: vector compares and scalar popcounts instead
+    //  of a shuffle reduction, whose six dependent ds_bpermute round trips cost more than the rest of this function)
+    uint32_t removed = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) removed += (uint32_t)__popcll(__ballot(((Bm >> k) & 1u) != 0u));
     wave_rm += removed;
     // New summary.  Heads and tails only change when a match touches one of the first two or
     // last two live tokens; a trailing run of equal tokens (tail_run > 1) is recounted.
@@ -2951,17 +3017,24 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                 tt_rename<MODE>(s, h, ti, run_in[tile]);
                 renamed = true;
             }
-            uint32_t Am = 0;             // bit j: slot j starts a match
+            // (the two tests on the tile's left edge -- does the previous tile's last token start a match with this
+            //  tile's first one, did it end one -- are uniform LDS reads; issued here they travel with the eight below
+            //  instead of costing a round trip of their own inside fused_tile_full)
+            const bool tcin = pair_test(lut, h.p1, tile_first & idmask);
+            const bool tbin = h.p2 != kHole && pair_test(lut, h.p2, h.p1 & idmask);
+            uint32_t Am = 0, Wm = 0;     // bit j: slot j starts a match / ... of the second key of its lookup bucket
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
-                const bool hit = pair_hit(lut, s[j], MODE == 1 ? cj[j] & idmask : cj[j]);     // (ids are 16-bit: no mask needed)
+                bool second_key;
+                const bool hit = pair_hit2(lut, s[j], MODE == 1 ? cj[j] & idmask : cj[j], second_key);     // (ids are 16-bit: no mask needed)
                 Am = Am + Am + (hit ? 1u : 0u);         // one add-with-carry, the carry being the compare mask
+                Wm = Wm + Wm + (second_key ? 1u : 0u);
             }
             const bool any = Am != 0u;
             if (DIAG == 3 || DIAG == 5) {    // timing-only build: membership tests, no merge
                 asm volatile("" :: "v"(Am));
-            } else if (__ballot(any) != 0ull || pair_test(lut, h.p1, tile_first & idmask)) {
-                outq = fused_tile_full<MODE, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, m_live, c_init, h, tile_first,
+            } else if (__ballot(any) != 0ull || tcin) {
+                outq = fused_tile_full<MODE, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, Wm, tcin, tbin, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
                                                 wave_rm, wrote_sum, lr_rsrc);
             }
@@ -3039,7 +3112,8 @@ __global__ __launch_bounds__(256) void k_delta_max(const uint32_t *__restrict__ 
 // How many pairs of the batch the sequential algorithm would really have chosen in this order
 // (see above).  Then the deltas of the surviving prefix are made exact for "only the prefix is
 // merged", and the argmax bounds of the dropped pairs are restored.
-constexpr int kValThreads = kBatchMax < 256 ? 256 : kBatchMax;
+constexpr int kValThreads = kBatchMax < 256 ? 256 : kBatchMax > 1024 ? 1024 : kBatchMax;
+constexpr int kValSlots = kBatchMax < 256 ? 256 : kBatchMax;      // pairs the workgroup scans: kValSlots / kValThreads per thread
 // The pairs that only exist through touching matches, folded into maxp[] with the whole chip (the n x n block
 // of ADJ is mostly zeros; one thread per cell).  After k_adj_sums (adj_in / adj_out) and before k_validate.
 __global__ __launch_bounds__(256) void k_adj_max(const uint32_t *__restrict__ hdr_adj, BatchState *bs, const DevCtl *ctl) {
@@ -3066,8 +3140,9 @@ __global__ __launch_bounds__(256) void k_adj_max(const uint32_t *__restrict__ hd
 
 __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m,
                                                           uint32_t *hdr_adj, uint32_t *LR) {
-    static_assert(kBatchMax <= 1024, "one workgroup validates a batch, a thread per pair");
-    __shared__ unsigned long long s_run[kValThreads];
+    static_assert(kValSlots % kValThreads == 0, "one workgroup validates a batch, kValSlots / kValThreads pairs per thread");
+    constexpr uint32_t kPer = kValSlots / kValThreads;
+    __shared__ unsigned long long s_run[kValSlots];
     __shared__ uint32_t s_commit, s_minfrac;
     const uint32_t tid = threadIdx.x;
     const uint32_t n = ctl->batch_n;
@@ -3075,22 +3150,30 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
     if (tid == 0) s_minfrac = 0xFFFFFFFFu;
     const uint32_t X0 = 256u + ctl->k_done;
     const uint32_t pitch = lr_pitch(X0);
-    s_run[tid] = tid < n ? bs->maxp[tid] : 0ull;
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) { const uint32_t p = tid + u * kValThreads; s_run[p] = p < n ? bs->maxp[p] : 0ull; }
     if (tid == 0) s_commit = n;
     __syncthreads();
     // (the pairs that only exist through touching matches were folded into maxp by k_adj_max)
     uint32_t nsh = 6;
     while ((1u << nsh) < n) ++nsh;
-    for (uint32_t d = 1; d < (uint32_t)kValThreads; d <<= 1) {        // inclusive prefix maximum
-        const unsigned long long o = tid >= d ? s_run[tid - d] : 0ull;
+    for (uint32_t d = 1; d < (uint32_t)kValSlots; d <<= 1) {        // inclusive prefix maximum
+        unsigned long long o[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) { const uint32_t p = tid + u * kValThreads; o[u] = p >= d ? s_run[p - d] : 0ull; }
         __syncthreads();
-        if (o > s_run[tid]) s_run[tid] = o;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) { const uint32_t p = tid + u * kValThreads; if (o[u] > s_run[p]) s_run[p] = o[u]; }
         __syncthreads();
     }
     // (`first` mode: a created pair with the SAME count would be ranked by position, which a batch cannot know)
-    if (tid >= 1 && tid < n &&
-        (ctl->first_mode ? (bs->packed[tid] >> 32) <= (s_run[tid - 1] >> 32) : bs->packed[tid] <= s_run[tid - 1]))
-        atomicMin(&s_commit, tid);
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint32_t p = tid + u * kValThreads;
+        if (p >= 1 && p < n &&
+            (ctl->first_mode ? (bs->packed[p] >> 32) <= (s_run[p - 1] >> 32) : bs->packed[p] <= s_run[p - 1]))
+            atomicMin(&s_commit, p);
+    }
     // candidates the selection passed over because an earlier member eats some of their occurrences:
     // (c, a_i) loses L_i[c], (b_i, d) loses R_i[d].  With those measured, the candidate must rank below
     // every member chosen after it; the batch ends at the first member it still beats.
@@ -3151,10 +3234,14 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
             hdr_adj[i] = 0;
         }
     }
-    if (tid >= commit && tid < n) {
-        const uint32_t e = bs->eidx[tid];
-        atomicMax(&t.bmax[e >> kBlockShift], bs->packed[tid]);
-        atomicMax(&t.smax[e >> (2 * kBlockShift)], bs->packed[tid]);
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint32_t p = tid + u * kValThreads;
+        if (p >= commit && p < n) {
+            const uint32_t e = bs->eidx[p];
+            atomicMax(&t.bmax[e >> kBlockShift], bs->packed[p]);
+            atomicMax(&t.smax[e >> (2 * kBlockShift)], bs->packed[p]);
+        }
     }
     if (tid == 0) {
         // (k_sel_pick ends a batch where a passed-over candidate, less this fraction, would still beat the next member)
