@@ -240,7 +240,10 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *   "compact_den"   compact when holes * den >= slots (default 16; 0 = never)
  *   "batch"         sequences (or single merges) per host round trip (default 16)
  *   "multi_merge"   1 = several independent merges per stream pass (default), 0 = one
- *   "max_batch"     most merges one pass may take (default and limit 1024)
+ *   "max_batch"     most merges one pass may take (default 2048, limit 4096; 1024 when the stream
+ *                   is sharded over several GPUs, whose exchange grows with it)
+ *   "byte_table"    1 = a batch whose pairs are all pairs of raw bytes is looked up in a byte x byte
+ *                   table by the stream kernels (default), 0 = always the hashed batch table
  *   "fused_min"     batches of at least this many pairs read the stream once and write
  *                   the merged stream to the second buffer (default 24; frequent pairs
  *                   qualify earlier); 2 = every multi-pair batch, >= 1000 = never
@@ -249,7 +252,7 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *   "threshold_select" 1 = choose batches from a gathered, sorted candidate list
  *                   (default), 0 = always walk the argmax bounds pair by pair
  *   "sel_cap"       capacity of the candidate list of the threshold selection (default and
- *                   limit 4096, at least 64; tests lower it to force the overflow path)
+ *                   limit 8192, at least 64; tests lower it to force the overflow path)
  *   "pc_repeat"     mbpe_pair_count_u8 called without an output table launches the scan this many times
  *                   back to back and reports the mean duration in mbpe_stats.ms_pair_count (timing only)
  *   "hier_argmax"   -1 auto / 0 scan every entry / 1 walk the block bounds

@@ -1717,7 +1717,15 @@ static_assert(kBatchMax <= 65536, "batch indices are stored in 16 bits");
 // second, 4-byte read per test: 144 KB of LDS, batches of 2,048 pairs with -DMBPE_BATCH_MAX=2048) was built and measured
 // in round 3: the fused pass went from 8.3 to 10.5 ms at the same batch size -- every LDS read in the per-slot path costs
 // as much as eight vector instructions -- which the 7 passes it saved (83 -> 76) do not pay back.
-struct BatchLutMem {             // (in LDS, one per workgroup)
+// The other form of the table, for batches whose pairs are all pairs of raw bytes (BatchState::byte_lut): the batch index
+// of (first, second) at [first][second], 0xFFFF where there is none -- ONE 2-byte LDS read per test, no hash, no key
+// compare, no limit on the batch but kBatchMax.  Row 256 and the last column are all 0xFFFF: a first token that is no byte
+// (a merged token, a hole, a token with its chunk-end bit) is clamped to that row, a second one to that column.  Columns
+// 256 .. 256 + kTTMax - 1 are the stand-in ids of (t,t) members (tt_rename).  First phase of every byte-level BPE, and all
+// of the benchmark's 31,744 merges (uniform bytes: every pair of merged tokens is ~256 times rarer than a byte pair).
+constexpr uint32_t kByteCols = 256u + (uint32_t)kTTMax + 1u;         // 273: bytes, stand-ins, "no"
+constexpr uint32_t kByteRows = 257u;
+struct BatchLutHash {
 #if MBPE_LUT_KEYS == 2
     uint2 bucket[kBuckets];
     uint32_t bidx[kBuckets];     // batch index of bucket.x (low half) and bucket.y (high half)
@@ -1731,6 +1739,11 @@ struct BatchLutMem {             // (in LDS, one per workgroup)
     uint2 bidx[kBuckets];        // batch indices of bucket.x .. bucket.w, 16 bits each
 #endif
 };
+struct BatchLutMem : BatchLutHash {             // (in LDS, one per workgroup: the hash form, or -- over the same bytes -- the byte form)
+    uint16_t byte_tail[kByteRows * kByteCols > sizeof(BatchLutHash) / 2 ? kByteRows * kByteCols - sizeof(BatchLutHash) / 2 : 1];
+    __device__ __forceinline__ uint16_t *byte_tab() { return reinterpret_cast<uint16_t *>(this); }
+};
+static_assert(sizeof(BatchLutMem) >= kByteRows * kByteCols * 2, "the byte table overlays the hash table");
 // The hash of a batch's table is second * mul + first (one v_mad_u32_u24), masked; mul is chosen per batch by the
 // selection among kHashMul so that no bucket needs a third key for as long as possible (BatchState::hash_mul) and
 // reaches the stream kernels in a scalar register.
@@ -1743,8 +1756,23 @@ static_assert(kHashSeeds >= 1 && kHashSeeds <= 8, "kHashMul");
 struct BatchLut {
     BatchLutMem *m;
     uint32_t mul;                // uniform
-    __device__ __forceinline__ BatchLut(BatchLutMem *mem, const BatchState *bs) : m(mem), mul(rfl(bs->hash_mul)) {}
+    bool bytes;                  // uniform: the byte form
+    uint32_t idmask;             // 0x7FFF with chunk-end bits in the slots, else 0xFFFF (where the stand-in ids lie)
+    __device__ __forceinline__ BatchLut(BatchLutMem *mem, const BatchState *bs, uint32_t idmask_)
+        : m(mem), mul(rfl(bs->hash_mul)), bytes(rfl(bs->byte_lut) != 0u), idmask(idmask_) {}
 };
+
+// byte form: the table entry of (first, second); first: any raw slot value, second: a token id (or kHole)
+template <bool TT>
+__device__ __forceinline__ uint32_t byte_entry(const BatchLut &lut, uint32_t first, uint32_t second, uint32_t idmask) {
+    const uint32_t r = first < 256u ? first : 256u;
+    uint32_t c = second < 256u ? second : kByteCols - 1u;
+    if (TT) {                     // a stand-in id (idmask - 1 - i) is column 256 + i
+        const uint32_t i = idmask - 1u - second;
+        c = i < (uint32_t)kTTMax ? 256u + i : c;
+    }
+    return lut.m->byte_tab()[r * kByteCols + c];
+}
 
 __device__ __forceinline__ uint32_t pair_hash(uint32_t mul, uint32_t first, uint32_t second) {
     return (__umul24(second, mul) + first) & (kBuckets - 1u);      // one v_mad_u32_u24
@@ -1793,6 +1821,28 @@ __device__ __forceinline__ void tt_flush(TTInfo &ti, uint32_t *hdr_m) {
 }
 
 __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys, uint32_t fake) {
+    if (lut.bytes) {
+        uint32_t *tw = reinterpret_cast<uint32_t *>(lut.m->byte_tab());
+        for (uint32_t i = threadIdx.x; i < (kByteRows * kByteCols + 1u) / 2u; i += blockDim.x) tw[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        uint16_t *tab = lut.m->byte_tab();
+        // (no two pairs share a cell: every thread places its own; the (t,t) members take their stand-in columns in
+        //  batch order, like tt_build)
+        for (uint32_t j = threadIdx.x; j < n_keys; j += blockDim.x) {
+            const uint32_t key = bs->key[j];
+            const uint32_t a = key >> 16, b = key & 0xFFFFu;
+            if (a != b) tab[a * kByteCols + b] = (uint16_t)j;
+        }
+        if (threadIdx.x == 0 && bs->tt_index != kNoTT) {
+            uint32_t n_tt = 0;
+            for (uint32_t j = bs->tt_index; j < n_keys && n_tt < (uint32_t)kTTMax; ++j) {
+                const uint32_t key = bs->key[j];
+                if ((key >> 16) == (key & 0xFFFFu)) tab[(key >> 16) * kByteCols + 256u + n_tt++] = (uint16_t)j;
+            }
+        }
+        __syncthreads();
+        return;
+    }
     uint32_t *words = reinterpret_cast<uint32_t *>(lut.m->bucket);
     constexpr uint32_t kMainKeys = kBucketKeys == 3 ? 2u : kBucketKeys;      // keys per bucket in `bucket`
     for (uint32_t i = threadIdx.x; i < kBuckets * kMainKeys; i += blockDim.x) words[i] = kEmptyPair;
@@ -1831,6 +1881,7 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
 // is (first, second) a batch pair?  first may be any raw slot value (a hole or a
 // token with the chunk-end bit never matches), second the id of the next live token
 __device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, uint32_t second) {
+    if (lut.bytes) return byte_entry<true>(lut, first, second, lut.idmask) != 0xFFFFu;
     const uint32_t hh = pair_hash_u(lut.mul, first, second);
     const auto bk = lut.m->bucket[hh];
     const uint32_t kk = first | (second << 16);
@@ -1847,6 +1898,7 @@ __device__ __forceinline__ bool pair_test(const BatchLut &lut, uint32_t first, u
 // hash with one v_mad_u32_u24, no boolean materialised.  Returns 0 iff (first, second) is a
 // batch pair, something non-zero otherwise.
 __device__ __forceinline__ uint32_t pair_miss(const BatchLut &lut, uint32_t first, uint32_t second) {
+    if (lut.bytes) return byte_entry<true>(lut, first, second, lut.idmask) ^ 0xFFFFu ? 0u : 1u;
     uint32_t h;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(lut.mul), "v"(first));
     const auto bk = lut.m->bucket[h & (kBuckets - 1u)];
@@ -1868,6 +1920,7 @@ __device__ __forceinline__ uint32_t pair_miss(const BatchLut &lut, uint32_t firs
 // ... and as a per-lane boolean, which the compiler keeps as a wave mask in scalar registers: one
 // compare per key, and the results combine on the scalar unit.
 __device__ __forceinline__ bool pair_hit(const BatchLut &lut, uint32_t first, uint32_t second) {
+    if (lut.bytes) return byte_entry<true>(lut, first, second, lut.idmask) != 0xFFFFu;
     uint32_t h;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(second), "s"(lut.mul), "v"(first));
     const auto bk = lut.m->bucket[h & (kBuckets - 1u)];
@@ -1900,6 +1953,7 @@ __device__ __forceinline__ bool pair_hit2(const BatchLut &lut, uint32_t first, u
 
 // index of the pair (only called for pairs that passed pair_test)
 __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, uint32_t second) {
+    if (lut.bytes) return (int)byte_entry<true>(lut, first, second, lut.idmask);
     const uint32_t h = pair_hash_u(lut.mul, first, second);
     const uint32_t kk = first | (second << 16);
 #if MBPE_LUT_KEYS == 2
@@ -1921,6 +1975,7 @@ __device__ __forceinline__ int lut_index(const BatchLut &lut, uint32_t first, ui
 
 // the same when the membership test has already told which key of the bucket matched (pair_hit2)
 __device__ __forceinline__ uint32_t lut_index_known(const BatchLut &lut, uint32_t first, uint32_t second, bool second_key) {
+    if (lut.bytes) return byte_entry<true>(lut, first, second, lut.idmask);
 #if MBPE_LUT_KEYS == 2
     const uint32_t ix = lut.m->bidx[pair_hash_u(lut.mul, first, second)];
     return second_key ? ix >> 16 : ix & 0xFFFFu;
@@ -2063,6 +2118,7 @@ __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevC
             bs->packed[accepted] = cand;
             bs->maxp[accepted] = 0;
             bs->hash_mul = kHashMul[0];
+            bs->byte_lut = 0;
             bs->skip_n = 0;                 // (this kernel ends the batch at a dependent pair
             bs->tt_index = kNoTT;           //  and merges a (t,t) pair alone)
             bs->tt_n = 0;
@@ -2176,7 +2232,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                                                            unsigned long long *best, uint32_t n_target,
                                                            uint32_t max_batch, uint32_t fused_min,
                                                            uint32_t n_ranks, int attempt, uint32_t fake_id, uint32_t sel_cap,
-                                                           uint32_t tt_max) {
+                                                           uint32_t tt_max, uint32_t byte_table) {
     __shared__ unsigned long long sp[kSelCap];
     __shared__ uint32_t si[kSelCap];
     // what the members accepted so far occupy (the independence test of a candidate is then a few LDS reads,
@@ -2196,7 +2252,8 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
     const uint32_t k_limit = ctl->k_limit < n_target ? ctl->k_limit : n_target;
     const uint32_t n_all = ctl->sel_n;          // entries >= T (the list holds the first kSelCap of them)
     const unsigned long long T = ctl->sel_T;
-    const uint32_t adapt = ctl->adapt_limit ? ctl->adapt_limit : (uint32_t)kBatchMax;
+    // (the batch size the candidate window is sized for: what validation has let through lately, at most the caller's cap)
+    const uint32_t adapt = min(ctl->adapt_limit ? ctl->adapt_limit : (uint32_t)kBatchMax, max_batch < 16u ? 16u : max_batch);
     const bool bounds_only = ctl->sel_mode != 0;
     __syncthreads();
     if (tid == 0) { ctl->sel_n = 0; ctl->sel_ok = 0; ctl->sel_retry = 0; ctl->sel_mode = 0; }
@@ -2297,6 +2354,9 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         uint32_t n_tt = 0;                          // (t,t) members so far, and the map slots they occupy
         unsigned long long tt_slots[kTTSlots / 64] = {};
         uint32_t alive = (1u << kHashSeeds) - 1u;   // hash multipliers under which every bucket still holds its keys
+        // every member so far is a pair of raw bytes (a (t,t) member: its token is): such a batch is looked up in the direct
+        // byte x byte table and needs no room in the hash buckets (BatchState::byte_lut)
+        bool all_bytes = byte_table != 0u;
         if (tid == 0) bs->tt_index = kNoTT;
         unsigned long long cand_next = n_l ? sp[0] : 0ull;         // (the next candidate is read one step ahead)
         for (; accepted < limit && ci < n_l; ++ci) {
@@ -2325,7 +2385,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             if (accepted > 0) {
                 // dependent on an earlier member (c, d): b == c or a == d
                 const bool conf = (((set_first[b >> 5] >> (b & 31u)) | (set_second[a >> 5] >> (a & 31u))) & 1u) != 0u;
-                const bool no_bucket = (alive & ~full) == 0u;
+                const bool no_bucket = (alive & ~full) == 0u && !(all_bytes && a < 256u && b < 256u);
                 if (single) { cut = 3u; break; }
                 if (conf && n_skip < (uint32_t)kSkipMax && skip_allowed) {
                     // Depends on an earlier member (shares a token with it the wrong way round): the
@@ -2352,6 +2412,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 if (cand < skip_floor) { cut = 1u; break; }
             }
             alive &= ~full;
+            all_bytes = all_bytes && a < 256u && b < 256u;
             if (seed_lane && ((alive >> tid) & 1u))
                 bucket_fill[tid][my_h / kFillPerWord] += 1u << ((my_h % kFillPerWord) * kFillBits);
             if (l0) {
@@ -2380,6 +2441,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         if (tid == 0) {
             bs->skip_n = n_skip; bs->tt_n = n_tt; ctl->n_skipped += n_skip;
             bs->hash_mul = kHashMul[alive ? (uint32_t)__builtin_ctz(alive) : 0u];
+            bs->byte_lut = all_bytes && accepted >= 2u ? 1u : 0u;
         }
         if (tid == 0) {
             ctl->batch_n = accepted;
@@ -2615,7 +2677,7 @@ template <int MODE, int DIAG = 0>
 __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, const uint32_t s[8], const Halo h,
                                                const BatchLut &lut, uint32_t n_keys, uint32_t *hdr_adj,
                                                uint32_t *LR, uint32_t pitch, DeltaCache &dc, bool dc_on, bool tt_on,
-                                               TTInfo &ti) {
+                                               TTInfo &ti, uint32_t adj_pitch) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     const Neigh nb = tile_neighbours(s, h);
@@ -2653,7 +2715,7 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
             if (left_open<MODE>(p1)) {
                 if (p2 != kHole && pair_test(lut, p2, p1)) {               // two matches touch
                     const int jp = lut_index(lut, p2, p1);
-                    atomicAdd(&hdr_adj[jp * kBatchMax + ja], 1u);
+                    atomicAdd(&hdr_adj[jp * adj_pitch + ja], 1u);
                 } else {
                     if (DIAG != 3) dc_add(dc, dc_on, LR, lr_idx(pitch, p1, (uint32_t)ja, 0), 1u);
                     else asm volatile("" :: "v"(ja));
@@ -2686,10 +2748,11 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     __shared__ TTInfo ti;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     const uint32_t pitch = rfl(lr_pitch(256u + ctl->k_done));
+    const uint32_t adj_pitch = rfl(ctl->adj_pitch);
     if (hot_mismatch<HOT>(bs->packed[0] >> 32, ctl, hot_launched)) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
-    BatchLut lut(&lut_mem, bs);
+    BatchLut lut(&lut_mem, bs, idmask);
     lut_build(lut, bs, n_keys, idmask - 1u);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
@@ -2745,7 +2808,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             const uint32_t tile_first = rlane(lf, (uint32_t)__builtin_ctzll(m_live | (1ull << 63)));
             bool work = __ballot(cand) != 0ull || pair_test(lut, h.p1, tile_first & idmask);
             if (DIAG == 2) { asm volatile("" :: "v"((uint32_t)cand)); work = false; }
-            if (work) scan_tile_full<MODE, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, pitch, dc, dc_on, TT, ti);
+            if (work) scan_tile_full<MODE, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, pitch, dc, dc_on, TT, ti, adj_pitch);
         }
         if (!v1) break;
         tile += n_waves;
@@ -2786,7 +2849,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
                                                  DeltaCache &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
-                                                 __amdgpu_buffer_rsrc_t lr_rsrc) {
+                                                 __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     const uint32_t pitch = lr_pitch(X0);        // uniform
@@ -2869,7 +2932,7 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
             nv = is_a ? (X0 + ja) | (cj[j] & endbit) : kHole;
             if (counted && DIAG != 2) {
                 if (is_a && ((touch >> j) & 1u)) {        // ... (a', b') (a, b): (b', a) -> (X', X)
-                    atomicAdd(&hdr_adj[pjb * kBatchMax + ja], 1u);
+                    atomicAdd(&hdr_adj[pjb * adj_pitch + ja], 1u);
                     delta_add(lr_idx(pitch, self, pjb, 1), 0xFFFFFFFFu);   // takes back the R count of (a', b')
                 } else {
                     delta_add(lr_idx(pitch, nb & idmask, ja, is_a ? 0u : 1u), 1u);
@@ -2950,7 +3013,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     if (hot_mismatch<HOT>(bs->packed[0] >> 32, ctl, hot_launched)) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
-    BatchLut lut(&lut_mem, bs);
+    BatchLut lut(&lut_mem, bs, idmask);
     lut_build(lut, bs, n_keys, idmask - 1u);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->marks_all = 1;
@@ -2963,6 +3026,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     const __amdgpu_buffer_rsrc_t sums_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
     const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(LR, 0, 0xFFFFFFFCu, 0x00020000);
+    const uint32_t adj_pitch = rfl(ctl->adj_pitch);
     TileIn t0 = tile_issue(tok, sums_rsrc, tile);
     TileIn t1 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + n_waves));
     bool v1 = (uint64_t)tile + n_waves < n_tiles;
@@ -3023,12 +3087,20 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             const bool tcin = pair_test(lut, h.p1, tile_first & idmask);
             const bool tbin = h.p2 != kHole && pair_test(lut, h.p2, h.p1 & idmask);
             uint32_t Am = 0, Wm = 0;     // bit j: slot j starts a match / ... of the second key of its lookup bucket
+            if (lut.bytes) {             // (uniform) a batch of byte pairs: one 2-byte read of the direct table per slot
 #pragma unroll
-            for (int j = 7; j >= 0; --j) {
-                bool second_key;
-                const bool hit = pair_hit2(lut, s[j], MODE == 1 ? cj[j] & idmask : cj[j], second_key);     // (ids are 16-bit: no mask needed)
-                Am = Am + Am + (hit ? 1u : 0u);         // one add-with-carry, the carry being the compare mask
-                Wm = Wm + Wm + (second_key ? 1u : 0u);
+                for (int j = 7; j >= 0; --j) {
+                    const bool hit = byte_entry<TT>(lut, s[j], MODE == 1 ? cj[j] & idmask : cj[j], idmask) != 0xFFFFu;
+                    Am = Am + Am + (hit ? 1u : 0u);
+                }
+            } else {
+#pragma unroll
+                for (int j = 7; j >= 0; --j) {
+                    bool second_key;
+                    const bool hit = pair_hit2(lut, s[j], MODE == 1 ? cj[j] & idmask : cj[j], second_key);     // (ids are 16-bit: no mask needed)
+                    Am = Am + Am + (hit ? 1u : 0u);         // one add-with-carry, the carry being the compare mask
+                    Wm = Wm + Wm + (second_key ? 1u : 0u);
+                }
             }
             const bool any = Am != 0u;
             if (DIAG == 3 || DIAG == 5) {    // timing-only build: membership tests, no merge
@@ -3036,7 +3108,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             } else if (__ballot(any) != 0ull || tcin) {
                 outq = fused_tile_full<MODE, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, Wm, tcin, tbin, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
-                                                wave_rm, wrote_sum, lr_rsrc);
+                                                wave_rm, wrote_sum, lr_rsrc, adj_pitch);
             }
         }
         // every tile's summary goes to the side array (an unchanged tile's as it was): no tile marks needed
@@ -3072,7 +3144,7 @@ __global__ __launch_bounds__(kWave) void k_adj_sums(const uint32_t *__restrict__
     if (n < 2) return;
     uint32_t in = 0, out = 0;
     if (j < n)
-        for (uint32_t p = threadIdx.x; p < n; p += kWave) { in += hdr_adj[p * kBatchMax + j]; out += hdr_adj[j * kBatchMax + p]; }
+        for (uint32_t p = threadIdx.x; p < n; p += kWave) { in += hdr_adj[p * ctl->adj_pitch + j]; out += hdr_adj[j * ctl->adj_pitch + p]; }
     in = wave_sum(in);
     out = wave_sum(out);
     if (threadIdx.x == 0) { bs->adj_in[j] = in; bs->adj_out[j] = out; }
@@ -3124,7 +3196,7 @@ __global__ __launch_bounds__(256) void k_adj_max(const uint32_t *__restrict__ hd
     const uint32_t n_waves = gridDim.x * (blockDim.x / kWave);
     for (uint32_t p = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; p < n; p += n_waves) {
         for (uint32_t q = lane_id(); q < n; q += kWave) {
-            const uint32_t w = hdr_adj[p * kBatchMax + q];
+            const uint32_t w = hdr_adj[p * ctl->adj_pitch + q];
             if (!w) continue;
             const uint32_t bp = bs->key[p] & 0xFFFFu, aq = bs->key[q] >> 16;
             // (maxp only grows: an atomic only where the value would still raise it)
@@ -3223,7 +3295,7 @@ __global__ __launch_bounds__(kValThreads) void k_validate(PairTable t, DevCtl *c
     for (uint32_t i2 = tid; i2 < (n << nsh); i2 += blockDim.x) {
         const uint32_t r = i2 >> nsh, q = i2 & ((1u << nsh) - 1u);
         if (q >= n) continue;
-        const uint32_t i = r * kBatchMax + q;
+        const uint32_t i = r * ctl->adj_pitch + q;
         const uint32_t w = hdr_adj[i];
         if (!w) continue;
         if (r >= commit && q < commit) {            // dropped match r directly before kept match q
@@ -3286,8 +3358,9 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
         }
     }
     // (the rows p < n of the ADJ block, whatever the grid)
-    for (uint64_t g = gid; g < (uint64_t)n * kBatchMax; g += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t p = (uint32_t)(g / kBatchMax), j = (uint32_t)(g % kBatchMax);
+    const uint32_t adj_pitch = ctl->adj_pitch;
+    for (uint64_t g = gid; g < (uint64_t)n * adj_pitch; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = (uint32_t)(g / adj_pitch), j = (uint32_t)(g % adj_pitch);
         const uint32_t adj = hdr_adj[g];
         if (adj) {
             hdr_adj[g] = 0;
@@ -3315,6 +3388,7 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
 // (neighbouring = runs of 32 contiguous cells in the tiled layout)
 // A new token's pairs are plain stores; their argmax bounds are raised once per wave.
 constexpr int kApplyTile = 64;
+constexpr uint32_t kApplyJParts = 16;
 
 // Inserting runs of neighbouring cells: dense_insert_store writes the cells (new pairs: plain stores) and hands back each
 // lane's packed value; the caller keeps a running maximum per tile and raises the argmax bounds once at the end
@@ -3349,10 +3423,12 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
     if (n < 2) return;
     const uint32_t commit = ctl->commit_n;
     const uint32_t X0 = 256u + ctl->k_done;
-    constexpr uint32_t j_parts = kBatchMax / kApplyTile;
-    const uint32_t x0 = (blockIdx.x / j_parts) * kApplyTile, j0 = (blockIdx.x % j_parts) * kApplyTile;
+    // (a workgroup takes 64 ids x and walks the pairs in steps of kApplyJParts tiles of 64: the grid does not grow
+    //  with the batch cap)
+    const uint32_t x0 = (blockIdx.x / kApplyJParts) * kApplyTile;
     const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
-    if (x0 < X0 && j0 < n) {
+    for (uint32_t j0 = (blockIdx.x % kApplyJParts) * kApplyTile; x0 < X0 && j0 < n; j0 += kApplyJParts * kApplyTile) {
+        __syncthreads();                 // (the tile of the previous step is done with)
         if (threadIdx.x < (uint32_t)kApplyTile) keys[threadIdx.x] = j0 + threadIdx.x < n ? bs->key[j0 + threadIdx.x] : 0u;
         // load (and clear) the deltas of ids x0.. and pairs j0..: the rows L_j, R_j of LR are contiguous along x
         const uint32_t pitch = lr_pitch(X0);
@@ -3437,11 +3513,13 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
         if (lane == 0 && n_new) atomicAdd(&ctl->n_entries, n_new);
     }
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < (uint64_t)kBatchMax * kBatchMax) {
-        const uint32_t p = (uint32_t)gid / kBatchMax, j = (uint32_t)gid % kBatchMax;
-        const uint32_t adj = hdr_adj[gid];
+    // (the rows p < n of the ADJ block, whatever the grid)
+    const uint32_t adj_pitch = ctl->adj_pitch;
+    for (uint64_t g = gid; g < (uint64_t)n * adj_pitch; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = (uint32_t)(g / adj_pitch), j = (uint32_t)(g % adj_pitch);
+        const uint32_t adj = hdr_adj[g];
         if (adj) {
-            hdr_adj[gid] = 0;
+            hdr_adj[g] = 0;
             if (p < commit && j < commit) {     // match of p directly followed by a match of j
                 const uint32_t bp = bs->key[p] & 0xFFFFu, aj = bs->key[j] >> 16;
                 table_add(t, ctl, (bp << 16) | aj, -(int32_t)adj, false);
@@ -3503,7 +3581,7 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
     const uint32_t X0 = 256u + ctl->k_done;
     const uint32_t n_list = ctl->n_marked;
     const bool marks_all = ctl->marks_all != 0u;
-    BatchLut lut(&lut_mem, bs);
+    BatchLut lut(&lut_mem, bs, idmask);
     lut_build(lut, bs, n_keys, idmask - 1u);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     const uint32_t lane = lane_id();
@@ -4041,7 +4119,7 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap) {
+                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap, bool byte_table) {
     const uint32_t fake_id = (endbit == kEndBit ? 0x7FFFu : 0xFFFFu) - 1u;      // see tt_rename
     // stand-in ids of (t,t) members are the kTTMax ids below the hole / end-bit mask: only while no token has them
     const uint32_t tt_max = 256u + n_target <= fake_id + 1u - (uint32_t)kTTMax ? (uint32_t)kTTMax : 1u;
@@ -4052,7 +4130,7 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
         for (int attempt = 0; attempt < 3; ++attempt) {
             hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target, sel_cap, attempt);
             hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
-                               fused_min, (uint32_t)n_ranks, attempt, fake_id, sel_cap, tt_max);
+                               fused_min, (uint32_t)n_ranks, attempt, fake_id, sel_cap, tt_max, byte_table ? 1u : 0u);
         }
     }
     hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch,
@@ -4148,9 +4226,8 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     hipLaunchKernelGGL(k_adj_max, dim3(kBatchMax / 4), dim3(256), 0, s, hdr_adj, bs, ctl);
     hipLaunchKernelGGL(k_validate, dim3(1), dim3(kValThreads), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     if (t.cells) {
-        uint32_t grid = ((id_upper + kApplyTile - 1) / kApplyTile) * (kBatchMax / kApplyTile);
-        const uint32_t need = (kBatchMax * kBatchMax + 255) / 256;          // the ADJ cells, one thread each
-        if (grid < need) grid = need;
+        uint32_t grid = ((id_upper + kApplyTile - 1) / kApplyTile) * kApplyJParts;
+        if (grid < 1024u) grid = 1024u;             // (the rows of the ADJ block and the per-pair part: a grid stride each)
         hipLaunchKernelGGL(k_apply_batch_dense, dim3(grid), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     } else {
         hipLaunchKernelGGL(k_apply_batch, dim3(blocks), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);

@@ -134,20 +134,26 @@ struct DevCtl {
     uint32_t first_tie;         // the selection took ONE pair whose count is shared: k_first_* pick the one that comes first
     uint32_t marks_all;         // the fused pass of this sequence wrote EVERY tile's summary to the side array and set no
                                 //   tile marks (its tiles nearly all change): "every tile is marked"
+    uint32_t adj_pitch;         // (host, at begin) row pitch of the ADJ block: the largest batch this training can select
+                                //   ("max_batch" rounded up to 64), so that the block -- and what several GPUs exchange of
+                                //   it -- is as small as the batches allow
 
 };
 
 // A batch holds up to kBatchMax pairs that can be merged in ONE pass over the
 // stream (see k_select_batch).  Per batch scratch, device memory:
 #ifndef MBPE_BATCH_MAX
-#define MBPE_BATCH_MAX 1024
+#define MBPE_BATCH_MAX 4096
 #endif
 constexpr int kBatchMax = MBPE_BATCH_MAX;
+// ("max_batch" when the caller sets none: the candidate list (kSelCap) has to hold a few batches' worth for the
+//  threshold of the gather to settle; at 4096 of 8192 it overflows or runs short every other sequence)
+constexpr int kBatchDefault = kBatchMax < 2048 ? kBatchMax : 2048;
 static_assert((kBatchMax & (kBatchMax - 1)) == 0 && kBatchMax >= 64,
               "a power of two: grid strides over the delta arrays keep a thread on one pair index");
 // candidates gathered by k_sel_scan
 #ifndef MBPE_SEL_CAP
-#define MBPE_SEL_CAP 4096
+#define MBPE_SEL_CAP 8192
 #endif
 constexpr uint32_t kSelCap = MBPE_SEL_CAP;
 struct SelList {
@@ -183,6 +189,10 @@ struct BatchState {
     // multiplier of the lookup-table hash for this batch: the selection tries several and keeps one under which no
     // bucket of the table has to hold a third key (kernels.hip: kHashMul, pair_hash)
     uint32_t hash_mul;
+    // every member is a pair of raw bytes (ids below 256; a (t,t) member's second token is its stand-in): the stream
+    // kernels then look pairs up in a direct table first byte x second byte instead of the hash table, which holds
+    // any batch up to kBatchMax pairs (the hash table's buckets end batches near 1,400)
+    uint32_t byte_lut;
     // candidates passed over because they depend on an earlier member of the batch (see k_sel_pick)
     uint32_t skip_n;
     uint32_t skip_key[kSkipMax];
@@ -191,8 +201,8 @@ struct BatchState {
 };
 
 // exchange buffer (u32 words): [single-merge header: m, adj, RankEdge x n_ranks]
-//   [batch header: m_j (kBatchMax), ADJ[i][j] (kBatchMax^2)] [LR: rows L_0, R_0, L_1, R_1, ... of lr_pitch(ids) cells]
-inline uint32_t batch_header_words() { return (uint32_t)(kBatchMax + kBatchMax * kBatchMax); }
+//   [batch header: m_j (kBatchMax), ADJ[i][j] (adj_pitch^2, row pitch DevCtl::adj_pitch)] [LR: rows L_0, R_0, L_1, R_1, ... of lr_pitch(ids) cells]
+inline uint32_t batch_header_words(uint32_t adj_pitch) { return (uint32_t)kBatchMax + adj_pitch * adj_pitch; }
 // row pitch of the LR block for a sequence that starts with `ids` token ids (256 + merges done): the ids rounded up
 // to 64 cells, so that rows start on 256-byte lines.  A batch of n pairs touches the first 2 * n * pitch cells.
 __host__ __device__ inline uint32_t lr_pitch(uint32_t ids) { return (ids + 63u) & ~63u; }
@@ -287,7 +297,7 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 // prefix), then k_select_batch (walks the argmax bounds one pair at a time) if that could not be used
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap);
+                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap, bool byte_table);
 // (three gather + pick attempts are enqueued: when the first gather overflows its list -- many equal
 //  counts -- the second lists the block bounds to find a threshold and the third gathers with it)
 // small batch: count the deltas and mark the tiles (the rewrite follows validation)

@@ -200,8 +200,9 @@ struct mbpe_ctx {
     int64_t opt_force_exchange = 0; // run the multi-rank path (edges, exchange) even with one rank
     int64_t opt_hier_argmax = -1;   // -1 auto (by table size), 0 full scan, 1 hierarchical
     int64_t opt_multi_merge = 1;    // 1: several independent merges per stream pass (batch sequences)
-    int64_t opt_max_batch = kBatchMax;
+    int64_t opt_max_batch = kBatchDefault;
     int64_t opt_fused_min = 24;     // batches of at least this many pairs take the fused pass
+    bool opt_byte_table = true;         // batches of byte pairs use the byte x byte lookup table (tests turn it off)
     int64_t opt_sel_cap = kSelCap;      // candidate-list capacity (tests lower it to force the overflow path)
     int64_t opt_threshold_select = 1;   // 0: always select with the bound-walking kernel
     int64_t opt_dense_table = -1;   // -1 auto / 1: dense pair table when vocab <= 32,768; 0: always hashed
@@ -213,6 +214,7 @@ struct mbpe_ctx {
     int64_t opt_first = 0;          // 1: `first` tie-break (insertion order, PairCount.h:65-74) instead of lexical
     int64_t opt_pc_repeat = 1;      // mbpe_pair_count_u8 without an output table: launches per call (timing)
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
+    uint32_t max_batch_eff = kBatchMax, adj_pitch = kBatchMax;   // (set by mbpe_train_begin: see begin_local)
     // multi-GPU: what the selection of the sequence in flight decided (k_done, k_limit, batch_n, commit_n of DevCtl),
     // read back while its stream pass runs, so that exactly the cells the batch can touch are exchanged
     uint32_t *h_seq = nullptr;      // pinned, 4 words
@@ -515,6 +517,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "chunk_barrier") c->opt_barrier = value < 0 ? -1 : value != 0;       // (read by the next mbpe_train_begin)
     else if (n == "first_batches") c->opt_first_batches = value != 0;
     else if (n == "sel_cap") c->opt_sel_cap = std::min<int64_t>(std::max<int64_t>(64, value), kSelCap);
+    else if (n == "byte_table") c->opt_byte_table = value != 0;
     else if (n == "pc_repeat") c->opt_pc_repeat = std::min<int64_t>(std::max<int64_t>(1, value), 1000);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
@@ -730,7 +733,11 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     if (c->n_slots / kTile > 0x0FFFFFF0ull) { mbpe_host::set_last_error("corpus shard too large"); return MBPE_ERR_ARG; }
     c->n_tiles = (uint32_t)(c->n_slots / kTile);
     c->hdr_words = exchange_header_words(c->n_ranks);
-    c->hdrb_words = (batch_header_words() + 3) / 4 * 4;
+    // the largest batch this training selects: "max_batch", and with several ranks at most 1,024 pairs -- the ADJ block
+    // (batch x batch) is part of what every sequence all-reduces
+    c->max_batch_eff = (uint32_t)std::min<int64_t>(c->opt_max_batch, is_multi(c) ? 1024 : kBatchMax);
+    c->adj_pitch = (uint32_t)round_up(std::max<uint32_t>(c->max_batch_eff, 64u), 64);
+    c->hdrb_words = (batch_header_words(c->adj_pitch) + 3) / 4 * 4;
     HIPCHK(tmalloc(c, &c->tok[0], c->n_slots * 2));
     HIPCHK(tmalloc(c, &c->tok[1], c->cap_slots * 2));
     HIPCHK(tmalloc(c, &c->sums, (size_t)c->n_tiles * sizeof(TileSum)));
@@ -768,6 +775,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
         init.n_live = n + n_bar;         // every corpus byte starts as one live token
         init.n_ranks = (uint32_t)std::max(1, c->n_ranks);
         init.first_mode = c->opt_first ? 1u : 0u;
+        init.adj_pitch = c->adj_pitch;
         c->h_ctl = init;
         HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl, sizeof(DevCtl), hipMemcpyHostToDevice, c->stream));
     }
@@ -914,8 +922,8 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     const bool multi = is_multi(c);
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
     launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best,
-                        c->n_target, (uint32_t)c->opt_max_batch, (uint32_t)c->opt_fused_min, c->n_cus,
-                        std::max(1, c->n_ranks), endbit, (uint32_t)c->opt_sel_cap);
+                        c->n_target, std::min<uint32_t>((uint32_t)c->opt_max_batch, c->max_batch_eff), (uint32_t)c->opt_fused_min, c->n_cus,
+                        std::max(1, c->n_ranks), endbit, (uint32_t)c->opt_sel_cap, c->opt_byte_table);
     if (c->opt_first)
         launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best, c->first_state, c->tok[0], c->tok[1], c->sums, c->n_tiles,
                               endbit, c->n_cus, 1);
@@ -939,7 +947,7 @@ static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge excha
     const uint32_t endbit = endbit_of(c);
     const bool multi = is_multi(c);
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
-    c->k_upper = std::min<uint32_t>(c->n_target, c->k_upper + (uint32_t)c->opt_max_batch);
+    c->k_upper = std::min<uint32_t>(c->n_target, c->k_upper + std::min<uint32_t>((uint32_t)c->opt_max_batch, c->max_batch_eff));
     const uint32_t id_upper = 256 + c->k_upper;
     launch_batch_tables(c->stream, c->tab, c->ctl, c->bs, c->hdr_m, c->hdr_adj, c->LR, id_upper);
     launch_apply(c->stream, c->tab, c->ctl, c->best, id_upper, c->LR, multi ? c->xb : nullptr, c->sums, c->side,

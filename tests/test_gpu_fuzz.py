@@ -11,7 +11,7 @@ from conftest import read_data
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 1024, "fused_min": 24,
+DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 4096, "fused_min": 24,
             "dense_table": -1, "threshold_select": 1, "sel_cap": 4096, "chunk_barrier": -1}
 
 
@@ -38,7 +38,7 @@ def _case(rng, text):
         cuts = np.unique(rng.integers(1, len(data), size=max(len(data) // int(rng.integers(2, 200)), 1)))
         off = np.concatenate([[0], cuts, [len(data)]]).astype(np.uint64)
     vocab = 256 + int(rng.integers(0, 400))
-    opts = {"max_batch": int(rng.choice([1, 2, 3, 7, 16, 64, 128, 256, 512, 1024])), "fused_min": int(rng.choice([2, 24, 1000])),
+    opts = {"max_batch": int(rng.choice([1, 2, 3, 7, 16, 64, 128, 256, 512, 1024, 4096])), "fused_min": int(rng.choice([2, 24, 1000])),
             "dense_table": int(rng.choice([0, 1])), "threshold_select": int(rng.choice([0, 1])),
             "sel_cap": int(rng.choice([64, 256, 4096])),
             "compact_den": int(rng.choice([0, 2, 8])), "batch": int(rng.choice([1, 3, 64])),

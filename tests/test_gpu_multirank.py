@@ -39,7 +39,9 @@ def _both_batch_paths(request):
 
 
 EXCHANGES = []        # (u32 words, merges committed before) of every exchange of the run in progress
-HDRB = (1024 + 1024 * 1024 + 3) // 4 * 4     # batch header of the exchange buffer: m_j, ADJ (kBatchMax = 1024)
+# batch header of the exchange buffer: m_j (kBatchMax = 4096 words) and the ADJ block, whose row pitch is the largest batch
+# a training selects -- 1,024 pairs with several ranks, so that the block stays 4 MB
+HDRB = (4096 + 1024 * 1024 + 3) // 4 * 4
 
 
 def _allreduce(trainers):

@@ -251,8 +251,8 @@ def test_train_tiny_inputs(tr, data, vocab):
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
-DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 1024, "fused_min": 24, "hier_argmax": -1,
-            "dense_table": -1, "threshold_select": 1, "sel_cap": 4096, "chunk_barrier": -1, "first_batches": 0}
+DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 2048, "fused_min": 24, "hier_argmax": -1,
+            "dense_table": -1, "threshold_select": 1, "sel_cap": 8192, "chunk_barrier": -1, "first_batches": 0, "byte_table": 1}
 
 
 def _defaults(tr):
@@ -610,11 +610,13 @@ def test_colliding_triples_really_collide():
         assert len({(b * mul + a) % 8192 for a, b in triple}) == 1
 
 
-@pytest.mark.parametrize("n_triples", [1, 3, 7, 8])
-def test_batch_lookup_switches_hash_multiplier(tr, n_triples):
+@pytest.mark.parametrize("n_triples,byte_table", [(1, 0), (3, 0), (7, 0), (8, 0), (8, 1)])
+def test_batch_lookup_switches_hash_multiplier(tr, n_triples, byte_table):
     """The top pairs of the corpus are chosen so that, rank after rank, the third key of a bucket appears under the
     first n_triples hash multipliers: the selection has to drop those and the stream kernels run with another one
-    (all eight used up: the batch ends there).  Merges, counts, stream and pair table against the oracle."""
+    (all eight used up: the batch ends there).  Pairs of raw bytes normally go through the byte x byte table, which
+    has no buckets to fill ("byte_table" 1: one batch holds all 24); "byte_table" 0 keeps them in the hashed one.
+    Merges, counts, stream and pair table against the oracle."""
     used = {x for t in _COLLIDING for p in t for x in p}
     seps = [x for x in range(1, 256) if x not in used]
     rng = np.random.default_rng(11)
@@ -633,6 +635,7 @@ def test_batch_lookup_switches_hash_multiplier(tr, n_triples):
     want_m, want_c = O.train(data, vocab)
     assert [tuple(x) for x in want_m[:3 * n_triples].tolist()] == [p for t in _COLLIDING[:n_triples] for p in t]
     tr.set_option("fused_min", 2)
+    tr.set_option("byte_table", byte_table)
     try:
         tr.load_corpus(data)
         tr.train_begin(vocab)
@@ -645,8 +648,8 @@ def test_batch_lookup_switches_hash_multiplier(tr, n_triples):
     finally:
         _defaults(tr)
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
-    if n_triples < 8:
-        assert first >= 3 * n_triples and st["cut_bucket"] == 0      # one batch held them all, under a later multiplier
+    if n_triples < 8 or byte_table:
+        assert first >= 3 * n_triples and st["cut_bucket"] == 0      # one batch held them all
     else:
         assert first == 23 and st["cut_bucket"] == 1                 # the 24th pair has no multiplier left
     ost = O.State(data, None)
