@@ -104,20 +104,25 @@ __device__ __forceinline__ uint32_t lr_idx(uint32_t pitch, uint32_t x, uint32_t 
 // atomics and written back once when the kernel ends; cells that lose the race for a slot go
 // straight to memory.  `on` (uniform) is only set for batches whose top pair is frequent
 // enough for this to matter; uniform-random corpora bypass the cache.
-constexpr uint32_t kDcSlots = 1024;
 constexpr uint32_t kDcEmpty = 0xFFFFFFFFu;
-struct DeltaCache {
-    uint32_t tag[kDcSlots];
-    uint32_t cnt[kDcSlots];
+template <int BITS>
+struct DeltaCacheT {
+    static constexpr uint32_t kSlots = 1u << BITS;
+    uint32_t tag[kSlots];
+    uint32_t cnt[kSlots];
 };
+typedef DeltaCacheT<10> DeltaCache;
+typedef DeltaCacheT<9> DeltaCacheSmall;      // (k_fused_batch: its lookup table and staging buffers leave 4 KB)
 
-__device__ __forceinline__ void dc_init(DeltaCache &dc) {
-    for (uint32_t i = threadIdx.x; i < kDcSlots; i += blockDim.x) { dc.tag[i] = kDcEmpty; dc.cnt[i] = 0; }
+template <class DC>
+__device__ __forceinline__ void dc_init(DC &dc) {
+    for (uint32_t i = threadIdx.x; i < DC::kSlots; i += blockDim.x) { dc.tag[i] = kDcEmpty; dc.cnt[i] = 0; }
 }
 
-__device__ __forceinline__ void dc_add(DeltaCache &dc, bool on, uint32_t *LR, uint32_t idx, uint32_t delta) {
+template <int BITS>
+__device__ __forceinline__ void dc_add(DeltaCacheT<BITS> &dc, bool on, uint32_t *LR, uint32_t idx, uint32_t delta) {
     if (on) {
-        const uint32_t slot = (idx * 0x9E3779B1u) >> 22;          // 10 bits
+        const uint32_t slot = (idx * 0x9E3779B1u) >> (32 - BITS);
         uint32_t t = dc.tag[slot];
         if (t == kDcEmpty) {
             t = atomicCAS(&dc.tag[slot], kDcEmpty, idx);
@@ -129,9 +134,10 @@ __device__ __forceinline__ void dc_add(DeltaCache &dc, bool on, uint32_t *LR, ui
 }
 
 // every thread of the workgroup, once all adds are done
-__device__ __forceinline__ void dc_flush(DeltaCache &dc, uint32_t *LR) {
+template <class DC>
+__device__ __forceinline__ void dc_flush(DC &dc, uint32_t *LR) {
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kDcSlots; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < DC::kSlots; i += blockDim.x) {
         const uint32_t c = dc.cnt[i];
         if (c) atomicAdd(&LR[dc.tag[i]], c);
     }
@@ -683,6 +689,47 @@ __device__ __forceinline__ void unpack8(const uint4 &q, uint32_t s[8]) {
 
 __device__ __forceinline__ uint4 pack8(const uint32_t s[8]) {
     return make_uint4(s[0] | (s[1] << 16), s[2] | (s[3] << 16), s[4] | (s[5] << 16), s[6] | (s[7] << 16));
+}
+
+// Every kernel that rewrites a tile leaves the tile's live tokens in its FIRST slots, in order, and the holes behind them
+// ("prefix form": k_widen and the compaction produce it, k_merge / k_rewrite_marked / k_fused_batch keep it), so the
+// token after a live slot is simply the next slot -- no chains over holes in the fused pass (fused_tile_pf).  (A
+// stream with barrier slots is compacted before its first pass: mbpe_train_begin.)
+// tile_compact: v[8] of all 64 lanes -> the lane's 8 slots of the compacted tile, packed; stage = this wave's 512
+// 16-bit slots of LDS (a wave's LDS operations execute in order: no barrier between its writes and its reads);
+// n_live (uniform) = live tokens of the tile.
+constexpr uint32_t kTileSlots = kWave * 8;
+__device__ __forceinline__ uint4 tile_compact(const uint32_t v[8], uint16_t *stage, uint32_t &n_live) {
+    const uint32_t lane = lane_id();
+    uint32_t keep = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) keep |= (v[j] != kHole ? 1u : 0u) << j;
+    const uint32_t cnt = (uint32_t)__popc(keep);         // 0 .. 8: the prefix sum over the lanes bit by bit, with ballots
+    uint32_t pos = 0, total = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b) {
+        const unsigned long long m = __ballot(((cnt >> b) & 1u) != 0u);
+        pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
+        total += (uint32_t)__popcll(m) << b;
+    }
+    n_live = total;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if ((keep >> j) & 1u) stage[pos] = (uint16_t)v[j];
+        pos += (keep >> j) & 1u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint4 q = *reinterpret_cast<const uint4 *>(stage + lane * 8u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int rem = (int)total - (int)(lane * 8u);       // live slots of this lane from here on (<= 0: none, >= 8: all)
+    q.x = rem >= 2 ? q.x : rem == 1 ? (q.x | 0xFFFF0000u) : 0xFFFFFFFFu;
+    q.y = rem >= 4 ? q.y : rem == 3 ? (q.y | 0xFFFF0000u) : 0xFFFFFFFFu;
+    q.z = rem >= 6 ? q.z : rem == 5 ? (q.z | 0xFFFF0000u) : 0xFFFFFFFFu;
+    q.w = rem >= 8 ? q.w : rem == 7 ? (q.w | 0xFFFF0000u) : 0xFFFFFFFFu;
+    return q;
 }
 
 __device__ __forceinline__ uint4 sum_to_u4(uint32_t head0, uint32_t head1, uint32_t tail1, uint32_t tail0,
@@ -1345,7 +1392,7 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
                                              uint32_t tile, uint32_t s[8], const Halo h, uint32_t a, uint32_t b,
                                              uint32_t X, uint32_t *LR, DeltaCache &dc, bool dc_on,
                                              const uint32_t *run_in,
-                                             uint32_t &wave_m, uint32_t &wave_adj, uint32_t &wave_rm) {
+                                             uint32_t &wave_m, uint32_t &wave_adj, uint32_t &wave_rm, uint16_t *stage) {
     const uint32_t pitch = lr_pitch(X);
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
@@ -1464,11 +1511,15 @@ __device__ __forceinline__ bool merge_tile_full(uint16_t *tok, const TileSum *si
         p2 = p1; p1 = self;       // neighbours are the OLD tokens
         if (nv != self) { changed = true; s[j] = nv; }
     }
-    if (changed) reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
     wave_m += my_m;
     wave_adj += my_adj;
     wave_rm += my_rm;
     if (__ballot(changed) == 0ull) return false;
+    {                                   // (the tile keeps its live tokens in its first slots: tile_compact)
+        uint32_t n_out;
+        const uint4 qc = tile_compact(s, stage, n_out);
+        reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = qc;
+    }
     const uint4 ns = wave_summary(s);
     if (lane == 0) {
         reinterpret_cast<uint4 *>(sout)[tile] = ns;
@@ -1489,6 +1540,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
                                                          const uint32_t *__restrict__ run_in, int hot_launched) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     __shared__ DeltaCache dc;
+    __shared__ __attribute__((aligned(16))) uint16_t stage_mem[kMergeThreads / kWave][kTileSlots];
+    uint16_t *stage = stage_mem[threadIdx.x / kWave];
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kMergeThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
@@ -1564,7 +1617,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge(uint16_t *tok0, uint16_
             bool work = __ballot(acc == 0u) != 0ull || h.p1 == a;
             if (DIAG == 2) { asm volatile("" :: "v"(acc)); work = false; }
             if (work) merge_tile_full<MODE>(tok, sin, sout, chg, n_tiles, tile, s, h, a, b, X, LR, dc, dc_on, run_in,
-                                                   wave_m, wave_adj, wave_rm);
+                                                   wave_m, wave_adj, wave_rm, stage);
         }
 
         if (!v1) break;
@@ -2840,7 +2893,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
 // live.  Everything else (pair index, neighbours, deltas) is only done where a
 // match is.
 
-template <int MODE, int DIAG = 0>
+template <int MODE, int DIAG = 0, class DC>
 __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on, TTInfo &ti,
                                                  const uint32_t s[8], const uint32_t cj[8],
                                                  uint32_t Am, uint32_t Wm, bool tcin, bool tbin, unsigned long long m_live,
@@ -2848,8 +2901,8 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
                                                  uint32_t tile_first, uint32_t old_x, uint32_t old_y,
                                                  uint32_t old_z, const BatchLut &lut, uint32_t X0, uint32_t tile,
                                                  TileSum *sout, uint32_t *chg, uint32_t *hdr_adj, uint32_t *LR,
-                                                 DeltaCache &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
-                                                 __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch) {
+                                                 DC &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
+                                                 __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     const uint32_t pitch = lr_pitch(X0);        // uniform
@@ -2976,7 +3029,139 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
     // (no tile mark: a fused pass writes every tile's summary to the side array, see DevCtl::marks_all)
     if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
     wrote_sum = true;
-    return pack8(out);
+    uint32_t n_out;
+    return tile_compact(out, stage, n_out);
+}
+
+// The same for a tile in prefix form (see tile_compact; every tile, unless the slots hold barriers): the token after a
+// slot is the next slot -- the next lane's first one, the next tile's first token after the last live slot -- and the
+// token before it the previous slot, so a slot is the second token of a match iff the slot before it starts one.  No
+// chains over holes, no carries over empty lanes, no (t,t) members (their instantiation takes fused_tile_full).  The
+// batch index of the match a slot starts is looked up once per slot (byte table: the entry itself) and handed to the
+// next two slots by register / DPP: a second token counts for the pair of the slot before it, a first token right
+// after a match for the pair two slots back (ADJ).  Same deltas, same new tile, same summary as fused_tile_full.
+template <int MODE, int DIAG = 0, class DC>
+__device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_t s[8], const Halo h,
+                                               uint32_t old_x, uint32_t old_y, uint32_t old_z, const BatchLut &lut,
+                                               uint32_t X0, uint32_t tile, TileSum *sout, uint32_t *hdr_adj, uint32_t *LR,
+                                               DC &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
+                                               __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage) {
+    constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
+    constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
+    constexpr uint32_t kNone = 0xFFFFu;          // "this slot starts no match" (batch indices are below kBatchMax)
+    const uint32_t pitch = lr_pitch(X0);        // uniform
+    auto delta_add = [&](uint32_t idx, uint32_t delta) {
+        if (dc_on) dc_add(dc, true, LR, idx, delta);
+        else __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)delta, lr_rsrc, idx << 2, 0, 0);
+    };
+    uint32_t lane = lane_id();
+    asm volatile("" : "+v"(lane));
+    const uint32_t live = old_z & 0xFFFFu;       // uniform, >= 1
+    const uint32_t tile_first = old_x & 0xFFFFu;
+    // the value after every slot
+    uint32_t n[8];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) n[j] = s[j + 1];
+    n[7] = wave_from_next(s[0], h.n1);
+    {
+        const uint32_t li = live - 1u;           // the last live slot: lane li / 8, slot li % 8
+        const bool mine = lane == (li >> 3);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j)
+            if ((li & 7u) == j) n[j] = mine ? h.n1 : n[j];
+    }
+    // the batch index of the match every slot starts
+    uint32_t idx[8];
+    if (lut.bytes) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) idx[j] = byte_entry<false>(lut, s[j], MODE == 1 ? n[j] & idmask : n[j], idmask);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t sec = MODE == 1 ? n[j] & idmask : n[j];
+            bool second_key;
+            const bool hit = pair_hit2(lut, s[j], sec, second_key);
+            idx[j] = kNone;
+            if (__ballot(hit) != 0ull) {
+                const uint32_t ix = lut_index_known(lut, s[j], sec, second_key);
+                idx[j] = hit ? ix : kNone;
+            }
+        }
+    }
+    if (DIAG == 3 || DIAG == 5) {                // timing-only build: lookups, no merge
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(idx[j]));
+        return q_orig;
+    }
+    // ... of the matches that reach into the tile from the left: (p1, first token) and (p2, p1); uniform
+    uint32_t in1 = kNone, in2 = kNone;
+    if (pair_test(lut, h.p1, tile_first & idmask)) in1 = (uint32_t)lut_index(lut, h.p1, tile_first & idmask);
+    if (h.p2 != kHole && pair_test(lut, h.p2, h.p1 & idmask)) in2 = (uint32_t)lut_index(lut, h.p2, h.p1 & idmask);
+    const uint32_t prev7 = wave_from_prev(idx[7] | (s[7] << 16), in1 | (h.p1 << 16));    // the slot before this lane's first
+    const uint32_t prev6 = wave_from_prev(idx[6], in2);                                  // ... and the one before that
+    const int lrem = (int)live - (int)(lane * 8u);
+    const uint32_t Lm = lrem >= 8 ? 0xFFu : lrem <= 0 ? 0u : (1u << lrem) - 1u;          // this lane's live slots
+    uint32_t Am = 0, Bm = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t pj = j == 0 ? (prev7 & 0xFFFFu) : idx[j - 1];
+        Am |= (idx[j] != kNone ? 1u : 0u) << j;
+        Bm |= (pj != kNone ? 1u : 0u) << j;
+    }
+    Bm &= Lm;            // (a match that starts at the tile's last live token ends in the next tile)
+    const uint32_t ABm = Am | Bm;
+    if (__ballot(ABm != 0u) == 0ull) return q_orig;
+
+    uint32_t out[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t self = s[j];
+        uint32_t nv = self;
+        if ((ABm >> j) & 1u) {
+            const uint32_t p1 = j == 0 ? prev7 >> 16 : s[j > 0 ? j - 1 : 0];
+            const uint32_t pj = j == 0 ? (prev7 & 0xFFFFu) : idx[j > 0 ? j - 1 : 0];
+            const uint32_t ppj = j == 0 ? prev6 : j == 1 ? (prev7 & 0xFFFFu) : idx[j > 1 ? j - 2 : 0];
+            if ((Am >> j) & 1u) {            // first token of a match: (p1, a) -> (p1, X)
+                const uint32_t ja = idx[j];
+                nv = (X0 + ja) | (n[j] & endbit);
+                if (left_open<MODE>(p1) && DIAG != 2) {
+                    if (ppj != kNone) {      // ... (a', b') (a, b): (b', a) -> (X', X)
+                        atomicAdd(&hdr_adj[ppj * adj_pitch + ja], 1u);
+                        delta_add(lr_idx(pitch, self, ppj, 1), 0xFFFFFFFFu);     // takes back the R count of (a', b')
+                    } else {
+                        delta_add(lr_idx(pitch, p1 & idmask, ja, 0u), 1u);
+                    }
+                }
+            } else {                         // second token: (b, n1) -> (X, n1)
+                nv = kHole;
+                if (right_open<MODE>(self, n[j]) && DIAG != 2) delta_add(lr_idx(pitch, n[j] & idmask, pj, 1u), 1u);
+            }
+        }
+        out[j] = nv;
+    }
+    uint32_t n_out;
+    const uint4 qc = tile_compact(out, stage, n_out);
+    wave_rm += live - n_out;
+    // New summary.  Heads and tails only change when a match touches one of the first two or last two live tokens; a
+    // trailing run of equal tokens (tail_run > 1) is recounted.
+    uint32_t em = lane == 0 ? 3u : 0u;
+    {
+        const uint32_t l1 = live - 1u, l2 = live >= 2u ? live - 2u : 0u;
+        em |= lane == (l1 >> 3) ? 1u << (l1 & 7u) : 0u;
+        em |= lane == (l2 >> 3) ? 1u << (l2 & 7u) : 0u;
+    }
+    const bool edge = __ballot((ABm & em) != 0u) != 0ull;
+    uint4 ns;
+    if (edge || (old_z >> 16) != 1u) {
+        uint32_t c[8];
+        unpack8(qc, c);
+        ns = wave_summary(c);
+    } else {
+        ns = make_uint4(old_x, old_y, (old_z & 0xFFFF0000u) | n_out, 0u);
+    }
+    if (lane == 0) reinterpret_cast<uint4 *>(sout)[tile] = ns;
+    wrote_sum = true;
+    return qc;
 }
 
 // (7 waves per SIMD: the cold instantiation meets it with two spilled registers, which is cheaper than
@@ -3001,12 +3186,16 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     const uint32_t lane = lane_id();
     const uint32_t waves_per_block = kLutThreads / kWave;
     const uint32_t n_waves = gridDim.x * waves_per_block;
-    __shared__ DeltaCache dc;
+    __shared__ DeltaCacheSmall dc;
     const uint32_t n_keys = ctl->batch_n;
     if (n_keys < 2 || !ctl->fused) return;
     // (the instantiation with the (t,t) code only runs for batches that have such a member, like HOT)
     if ((bs->tt_index != kNoTT) != TT) return;
     __shared__ TTInfo ti;
+    __shared__ __attribute__((aligned(16))) uint16_t stage_mem[kLutThreads / kWave][kTileSlots];
+    uint16_t *stage = stage_mem[threadIdx.x / kWave];
+    // tiles are in prefix form and take the short tile function (fused_tile_pf), except for batches with (t,t) members
+    constexpr bool PF = !TT;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     uint16_t *dst = ctl->cur ? tok0 : tok1;
     const uint32_t X0 = 256u + ctl->k_done;
@@ -3053,6 +3242,10 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             } else {
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
+            if constexpr (PF) {
+                outq = fused_tile_pf<MODE, DIAG>(t0.q, s, h, old_x, old_y, old_z, lut, X0, tile, sout, hdr_adj, LR, dc, dc_on,
+                                                 wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage);
+            } else {
             uint32_t lf, c_init, tile_first, cj[8];
             unsigned long long m_live;
             bool renamed = false;        // uniform: tt_rename ran on this tile (only then can stand-in ids occur in it)
@@ -3108,7 +3301,8 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             } else if (__ballot(any) != 0ull || tcin) {
                 outq = fused_tile_full<MODE, DIAG>(t0.q, TT && renamed, ti, s, cj, Am, Wm, tcin, tbin, m_live, c_init, h, tile_first,
                                                 old_x, old_y, old_z, lut, X0, tile, sout, chg, hdr_adj, LR, dc, dc_on,
-                                                wave_rm, wrote_sum, lr_rsrc, adj_pitch);
+                                                wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage);
+            }
             }
         }
         // every tile's summary goes to the side array (an unchanged tile's as it was): no tile marks needed
@@ -3389,6 +3583,10 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
 // A new token's pairs are plain stores; their argmax bounds are raised once per wave.
 constexpr int kApplyTile = 64;
 constexpr uint32_t kApplyJParts = 16;
+#ifndef MBPE_APPLY_FLIGHT
+#define MBPE_APPLY_FLIGHT 16
+#endif
+constexpr uint32_t kApplyFlight = MBPE_APPLY_FLIGHT;     // decrements (with their old values coming back) in flight per lane
 
 // Inserting runs of neighbouring cells: dense_insert_store writes the cells (new pairs: plain stores) and hands back each
 // lane's packed value; the caller keeps a running maximum per tile and raises the argmax bounds once at the end
@@ -3407,9 +3605,9 @@ __device__ __forceinline__ void dense_raise_bounds(const PairTable &t, unsigned 
         const uint32_t blk0 = rfl(__shfl(blk, (uint32_t)__builtin_ctzll(m), kWave));
         const bool mine = p != 0ull && blk == blk0;
         const unsigned long long pm = wave_max_u64(mine ? p : 0ull);
-        if (lane_id() == 0) {
-            if (pm > t.bmax[blk0]) atomicMax(&t.bmax[blk0], pm);
-            if (pm > t.smax[blk0 >> kBlockShift]) atomicMax(&t.smax[blk0 >> kBlockShift], pm);
+        if (lane_id() == 0) {               // (fire and forget: reading the bound first would be a round trip per tile)
+            atomicMax(&t.bmax[blk0], pm);
+            atomicMax(&t.smax[blk0 >> kBlockShift], pm);
         }
         m &= ~__ballot(mine);
     }
@@ -3432,39 +3630,48 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
         if (threadIdx.x < (uint32_t)kApplyTile) keys[threadIdx.x] = j0 + threadIdx.x < n ? bs->key[j0 + threadIdx.x] : 0u;
         // load (and clear) the deltas of ids x0.. and pairs j0..: the rows L_j, R_j of LR are contiguous along x
         const uint32_t pitch = lr_pitch(X0);
-        for (uint32_t c = wave; c < (uint32_t)kApplyTile; c += 256 / kWave) {
-            const uint32_t x = x0 + lane, j = j0 + c;
-            uint2 lr = make_uint2(0, 0);
-            if (x < X0 && j < n) {
-                uint32_t *cl = LR + (size_t)(2u * j) * pitch + x, *cr = cl + pitch;
-                lr = make_uint2(*cl, *cr);
-                if (lr.x) *cl = 0;
-                if (lr.y) *cr = 0;
-                if (j >= commit) lr = make_uint2(0, 0);
+        constexpr uint32_t kRows = kApplyTile / (256 / kWave);        // rows (columns) per wave: 16
+        {
+            // (all of a wave's loads are issued before the first store: the rows are independent, the compiler cannot know)
+            const uint32_t x = x0 + lane;
+            uint32_t vl[kRows], vr[kRows];
+#pragma unroll
+            for (uint32_t u = 0; u < kRows; ++u) {
+                const uint32_t j = j0 + wave + u * (256 / kWave);
+                const bool ok = x < X0 && j < n;
+                const uint32_t *cl = LR + (size_t)(2u * j) * pitch + x;
+                vl[u] = ok ? __builtin_nontemporal_load(cl) : 0u;
+                vr[u] = ok ? __builtin_nontemporal_load(cl + pitch) : 0u;
             }
-            tile[lane][c] = lr;
+#pragma unroll
+            for (uint32_t u = 0; u < kRows; ++u) {
+                const uint32_t c = wave + u * (256 / kWave), j = j0 + c;
+                uint32_t *cl = LR + (size_t)(2u * j) * pitch + x;
+                if (vl[u]) *cl = 0;
+                if (vr[u]) *(cl + pitch) = 0;
+                tile[lane][c] = j < commit ? make_uint2(vl[u], vr[u]) : make_uint2(0, 0);
+            }
         }
         __syncthreads();
         // The decrements return the old value (an absent pair or a negative count is an error worth
-        // knowing about); four of them are in flight per lane before the first one is looked at.
-        constexpr uint32_t kRows = kApplyTile / (256 / kWave);        // rows (columns) per wave: 16
+        // knowing about); kApplyFlight of them are in flight per lane before the first one is looked at.
         uint32_t err = 0, n_new = 0;
         // lanes along j: left neighbours x
         const uint32_t jl = j0 + lane;
         const uint32_t a = keys[lane] >> 16;
         // (new pairs (x, X_j): this lane's column X0 + jl, rows x0 .. x0 + 63 = two rows of tiles)
         unsigned long long accL[2] = {0ull, 0ull};
-        for (uint32_t r0 = 0; r0 < kRows; r0 += 4) {
-            uint32_t l[4], old[4];
+        for (uint32_t r0 = 0; r0 < kRows; r0 += kApplyFlight) {
+            uint32_t l[kApplyFlight], old[kApplyFlight];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kApplyFlight; ++u) {
                 const uint32_t r = wave + (r0 + u) * (256 / kWave), x = x0 + r;
                 l[u] = tile[r][lane].x;
                 old[u] = kPresent | l[u];
                 if (l[u]) old[u] = atomicAdd(&t.cells[dense_index(t, (x << 16) | a)], 0u - l[u]);
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kApplyFlight; ++u) {
                 const uint32_t r = wave + (r0 + u) * (256 / kWave), x = x0 + r;
                 const unsigned long long p = dense_insert_store(t, l[u] != 0u, dense_index(t, (x << 16) | (X0 + jl)),
                                                                 (x << 16) | (X0 + jl), l[u], n_new);
@@ -3472,7 +3679,7 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
                 accL[rb] = p > accL[rb] ? p : accL[rb];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u)
+            for (uint32_t u = 0; u < kApplyFlight; ++u)
                 err |= !(old[u] & kPresent) ? kErrMissingPair : ((old[u] & ~kPresent) < l[u] ? kErrNegCount : 0u);
         }
 #pragma unroll
@@ -3483,17 +3690,17 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
         // (new pairs (X_j, x): rows X0 + j0 .. + 63 = up to three rows of tiles, this lane's column xr)
         unsigned long long accR[3] = {0ull, 0ull, 0ull};
         const uint32_t Xrow0 = (X0 + j0) >> 5;
-        for (uint32_t c0 = 0; c0 < kRows; c0 += 4) {
-            uint32_t rr[4], old[4];
+        for (uint32_t c0 = 0; c0 < kRows; c0 += kApplyFlight) {
+            uint32_t rr[kApplyFlight], old[kApplyFlight];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kApplyFlight; ++u) {
                 const uint32_t c = wave + (c0 + u) * (256 / kWave), j = j0 + c;
                 rr[u] = j < n ? tile[lane][c].y : 0u;
                 old[u] = kPresent | rr[u];
                 if (rr[u]) old[u] = atomicAdd(&t.cells[dense_index(t, ((keys[c] & 0xFFFFu) << 16) | xr)], 0u - rr[u]);
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kApplyFlight; ++u) {
                 const uint32_t c = wave + (c0 + u) * (256 / kWave), X = X0 + j0 + c;
                 const unsigned long long p = dense_insert_store(t, rr[u] != 0u, dense_index(t, (X << 16) | xr), (X << 16) | xr,
                                                                 rr[u], n_new);
@@ -3503,7 +3710,7 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
                 else accR[2] = p > accR[2] ? p : accR[2];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u)
+            for (uint32_t u = 0; u < kApplyFlight; ++u)
                 err |= !(old[u] & kPresent) ? kErrMissingPair : ((old[u] & ~kPresent) < rr[u] ? kErrNegCount : 0u);
         }
 #pragma unroll
@@ -3578,6 +3785,8 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
     const uint32_t n_keys = ctl->commit_n;
     if ((bs->tt_index < n_keys) != TT) return;      // (t,t) member inside the kept prefix: see k_fused_batch
     __shared__ TTInfo ti;
+    __shared__ __attribute__((aligned(16))) uint16_t stage_mem[kLutThreads / kWave][kTileSlots];
+    uint16_t *stage = stage_mem[threadIdx.x / kWave];
     const uint32_t X0 = 256u + ctl->k_done;
     const uint32_t n_list = ctl->n_marked;
     const bool marks_all = ctl->marks_all != 0u;
@@ -3644,9 +3853,11 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
                 if (s[j] != kHole && (s[j] & idmask) >= idmask - (uint32_t)kTTMax)
                     s[j] = ti.tok[idmask - 1u - (s[j] & idmask)] | (s[j] & endbit);
         }
-        if (changed) reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = pack8(s);
         wave_rm += my_rm;
         if (__ballot(changed) != 0ull) {
+            uint32_t n_out;
+            const uint4 qc = tile_compact(s, stage, n_out);
+            reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = qc;
             const uint4 ns = wave_summary(s);
             if (lane == 0) {
                 reinterpret_cast<uint4 *>(sout)[tile] = ns;

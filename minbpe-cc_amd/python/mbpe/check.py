@@ -124,6 +124,19 @@ def decoded_length(tr, merges, torch, device, slots_per_piece=1 << 28):
     return total
 
 
+def tiles_in_prefix_form(tr, torch, device, slots_per_piece=1 << 28):
+    """Every 512-slot tile of the stream holds its live tokens in its first slots and its holes behind them: what the
+    stream kernels keep whenever they rewrite a tile (tile_compact in csrc/kernels.hip) and the fused pass relies on."""
+    ptr, n_slots, bits, end_bit, barrier = tr.stream_device()
+    assert bits == 16 and n_slots % 512 == 0
+    for lo in range(0, n_slots, slots_per_piece):
+        hi = min(lo + slots_per_piece, n_slots)
+        hole = (_as_tensor(torch, ptr + 2 * lo, hi - lo, torch.int16, device) == -1).view(-1, 512)
+        if bool((hole[:, :-1] & ~hole[:, 1:]).any()):       # a hole directly before a live slot
+            return False
+    return True
+
+
 def counts_nonincreasing(counts):
     c = np.asarray(counts, dtype=np.int64)
     return bool(np.all(np.diff(c) <= 0))

@@ -5,14 +5,17 @@ pair table against the CPU oracle."""
 import numpy as np
 import pytest
 
+import torch
+
 import mbpe
 import oracle as O
 from conftest import read_data
+from mbpe import check
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 4096, "fused_min": 24,
-            "dense_table": -1, "threshold_select": 1, "sel_cap": 4096, "chunk_barrier": -1}
+DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 2048, "fused_min": 24,
+            "dense_table": -1, "threshold_select": 1, "sel_cap": 8192, "chunk_barrier": -1}
 
 
 def _case(rng, text):
@@ -40,7 +43,7 @@ def _case(rng, text):
     vocab = 256 + int(rng.integers(0, 400))
     opts = {"max_batch": int(rng.choice([1, 2, 3, 7, 16, 64, 128, 256, 512, 1024, 4096])), "fused_min": int(rng.choice([2, 24, 1000])),
             "dense_table": int(rng.choice([0, 1])), "threshold_select": int(rng.choice([0, 1])),
-            "sel_cap": int(rng.choice([64, 256, 4096])),
+            "sel_cap": int(rng.choice([64, 256, 4096, 8192])),
             "compact_den": int(rng.choice([0, 2, 8])), "batch": int(rng.choice([1, 3, 64])),
             "multi_merge": int(rng.choice([0, 1, 1, 1])),
             "chunk_barrier": int(rng.choice([-1, 1]))}        # (chunk ends as barrier slots: tests/test_gpu_barrier.py)
@@ -75,4 +78,5 @@ def test_fuzz_against_oracle(seed):
                 assert np.array_equal(tr.stream()[0], st.stream()[0]), tag
             assert {k: v for k, v in tr.pairs_dict().items() if v} == \
                    {k: v for k, v in st.table_dict().items() if v}, tag
+            assert check.tiles_in_prefix_form(tr, torch, torch.device("cuda", 0)), tag
             st.close()

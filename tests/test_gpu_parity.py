@@ -6,9 +6,12 @@ import os
 import numpy as np
 import pytest
 
+import torch
+
 import mbpe
 import oracle as O
 from conftest import GOLDEN, read_data, read_golden
+from mbpe import check
 
 pytestmark = pytest.mark.gpu
 
@@ -301,6 +304,8 @@ def _step_parity(tr, data, off, vocab, stride=1, **opts):
             want_tab = {k_: v_ for k_, v_ in st.table_dict().items() if v_}
             got_tab = {k_: v_ for k_, v_ in tr.pairs_dict().items() if v_}
             assert got_tab == want_tab, "pair table differs at step %d" % i
+            # (every kernel that rewrites a tile keeps its live tokens in the tile's first slots: the fused pass relies on it)
+            assert check.tiles_in_prefix_form(tr, torch, torch.device("cuda", 0)), "a tile with a hole before a token at step %d" % i
             i += 1
     finally:
         _defaults(tr)
