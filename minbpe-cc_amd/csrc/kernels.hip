@@ -2410,6 +2410,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         // every member so far is a pair of raw bytes (a (t,t) member: its token is): such a batch is looked up in the direct
         // byte x byte table and needs no room in the hash buckets (BatchState::byte_lut)
         bool all_bytes = byte_table != 0u;
+        uint32_t tracked = 0, tracked_tt = 0;       // members (and (t,t) members among them) the bucket fills know
         if (tid == 0) bs->tt_index = kNoTT;
         unsigned long long cand_next = n_l ? sp[0] : 0ull;         // (the next candidate is read one step ahead)
         for (; accepted < limit && ci < n_l; ++ci) {
@@ -2428,17 +2429,36 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 if (tie && accepted > 0) { cut = 1u; break; }
                 if (tie) { single = true; if (l0) ctl->first_tie = 1; }
             }
-            // multipliers under which this key would be the bucket's (kBucketKeys + 1)-th: they drop out if it is accepted
-            const uint32_t b_hash = tt ? fake_id - n_tt : b;
-            const uint32_t my_h = pair_hash(my_mul, a, b_hash);
-            uint32_t my_f = 0;
-            if (seed_lane)
-                my_f = (bucket_fill[tid][my_h / kFillPerWord] >> ((my_h % kFillPerWord) * kFillBits)) & ((1u << kFillBits) - 1u);
-            const uint32_t full = (uint32_t)__ballot(seed_lane && my_f >= kBucketKeys);
+            // A pair of raw bytes in a batch of such pairs needs no room in the hash buckets (byte table); the bucket fills
+            // then lag behind and are caught up with -- members `tracked` .. accepted - 1 -- when a candidate needs them.
+            const bool byte_cand = all_bytes && a < 256u && b < 256u;
+            uint32_t my_h = 0, full = 0;
+            if (!byte_cand) {
+                for (; tracked < accepted; ++tracked) {
+                    const unsigned long long mc = sp[acc_ci[tracked]];
+                    const uint32_t mk = ~(uint32_t)mc, ma = mk >> 16, mb = mk & 0xFFFFu;
+                    const bool mtt = ma == mb && (uint32_t)(mc >> 32) != 0u;
+                    const uint32_t mh = pair_hash(my_mul, ma, mtt ? fake_id - tracked_tt : mb);
+                    tracked_tt += mtt ? 1u : 0u;
+                    uint32_t mf = 0;
+                    if (seed_lane)
+                        mf = (bucket_fill[tid][mh / kFillPerWord] >> ((mh % kFillPerWord) * kFillBits)) & ((1u << kFillBits) - 1u);
+                    alive &= ~(uint32_t)__ballot(seed_lane && mf >= kBucketKeys);
+                    if (seed_lane && ((alive >> tid) & 1u))
+                        bucket_fill[tid][mh / kFillPerWord] += 1u << ((mh % kFillPerWord) * kFillBits);
+                }
+                // multipliers under which this key would be the bucket's (kBucketKeys + 1)-th: they drop out if it is accepted
+                const uint32_t b_hash = tt ? fake_id - n_tt : b;
+                my_h = pair_hash(my_mul, a, b_hash);
+                uint32_t my_f = 0;
+                if (seed_lane)
+                    my_f = (bucket_fill[tid][my_h / kFillPerWord] >> ((my_h % kFillPerWord) * kFillBits)) & ((1u << kFillBits) - 1u);
+                full = (uint32_t)__ballot(seed_lane && my_f >= kBucketKeys);
+            }
             if (accepted > 0) {
                 // dependent on an earlier member (c, d): b == c or a == d
                 const bool conf = (((set_first[b >> 5] >> (b & 31u)) | (set_second[a >> 5] >> (a & 31u))) & 1u) != 0u;
-                const bool no_bucket = (alive & ~full) == 0u && !(all_bytes && a < 256u && b < 256u);
+                const bool no_bucket = !byte_cand && (alive & ~full) == 0u;
                 if (single) { cut = 3u; break; }
                 if (conf && n_skip < (uint32_t)kSkipMax && skip_allowed) {
                     // Depends on an earlier member (shares a token with it the wrong way round): the
@@ -2464,13 +2484,17 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                 if (conf || no_bucket) { cut = conf ? 1u : 2u; break; }
                 if (cand < skip_floor) { cut = 1u; break; }
             }
-            alive &= ~full;
-            all_bytes = all_bytes && a < 256u && b < 256u;
-            if (seed_lane && ((alive >> tid) & 1u))
-                bucket_fill[tid][my_h / kFillPerWord] += 1u << ((my_h % kFillPerWord) * kFillBits);
+            all_bytes = byte_cand;
+            if (!byte_cand) {
+                alive &= ~full;
+                if (seed_lane && ((alive >> tid) & 1u))
+                    bucket_fill[tid][my_h / kFillPerWord] += 1u << ((my_h % kFillPerWord) * kFillBits);
+                tracked = accepted + 1u;
+                tracked_tt = n_tt + (tt ? 1u : 0u);
+            }
             if (l0) {
-                set_first[a >> 5] |= 1u << (a & 31u);
-                set_second[b >> 5] |= 1u << (b & 31u);
+                atomicOr(&set_first[a >> 5], 1u << (a & 31u));          // (LDS atomics: no read to wait for)
+                atomicOr(&set_second[b >> 5], 1u << (b & 31u));
                 if (cnt_first[a & kCntFold] != 0xFFu) cnt_first[a & kCntFold] += 1;
                 if (cnt_second[b & kCntFold] != 0xFFu) cnt_second[b & kCntFold] += 1;
                 acc_ci[accepted] = (uint16_t)ci;
@@ -2480,6 +2504,8 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             ++accepted;
             if (single) { cut = 3u; ++ci; break; }
         }
+        // (a batch that goes through the hash table after all -- a single byte pair: no table at all -- is caught up with;
+        //  nothing can drop out any more: every member behind a non-byte one was tracked when it was accepted)
         // the members' records, all lanes at once
         for (uint32_t i = tid; i < accepted; i += kWave) {
             const uint32_t at = acc_ci[i];
@@ -3057,46 +3083,69 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
     uint32_t lane = lane_id();
     asm volatile("" : "+v"(lane));
     const uint32_t live = old_z & 0xFFFFu;       // uniform, >= 1
-    const uint32_t tile_first = old_x & 0xFFFFu;
-    // the value after every slot
+    const uint32_t tile_first = old_x & 0xFFFFu, tile_last = old_y >> 16;
+    // the value after every slot (after the last live slot: a hole, or the next tile's first token when the tile is full)
     uint32_t n[8];
 #pragma unroll
     for (int j = 0; j < 7; ++j) n[j] = s[j + 1];
     n[7] = wave_from_next(s[0], h.n1);
-    {
-        const uint32_t li = live - 1u;           // the last live slot: lane li / 8, slot li % 8
-        const bool mine = lane == (li >> 3);
-#pragma unroll
-        for (uint32_t j = 0; j < 8; ++j)
-            if ((li & 7u) == j) n[j] = mine ? h.n1 : n[j];
-    }
-    // the batch index of the match every slot starts
-    uint32_t idx[8];
-    if (lut.bytes) {
+    // The batch index of the match every slot starts (kNone: none) -- and of the three matches across the tile's edges,
+    // which lanes 0, 1, 2 look up in a ninth read: (p1, first token), (p2, p1), (last token, n1).
+    const uint32_t ef = lane == 0 ? h.p1 : lane == 1 ? h.p2 : lane == 2 ? tile_last : kHole;
+    const uint32_t es = (lane == 0 ? tile_first : lane == 1 ? h.p1 : h.n1) & idmask;
+    uint32_t idx[8], eidx;
+    if (lut.bytes) {             // (uniform) the byte table: the entry is the index
 #pragma unroll
         for (int j = 0; j < 8; ++j) idx[j] = byte_entry<false>(lut, s[j], MODE == 1 ? n[j] & idmask : n[j], idmask);
-    } else {
+        eidx = byte_entry<false>(lut, ef, es, idmask);
+        // nearly every tile of a small batch: no match anywhere (indices are 16-bit: all kNone iff their AND is)
+        const uint32_t all = idx[0] & idx[1] & idx[2] & idx[3] & idx[4] & idx[5] & idx[6] & idx[7] & eidx;
+        if (__ballot(all != kNone) == 0ull && DIAG != 3 && DIAG != 5) return q_orig;
+    } else {                     // the hash table: nine bucket reads, then the index words of the slots that hit
+        uint32_t Hm = 0, Wm = 0;         // bit j: slot j (8: the edge lookup) starts a match / ... under its bucket's second key
+        {
+            bool second_key;
+            const bool hit = pair_hit2(lut, ef, es, second_key);
+            Hm = hit ? 1u : 0u;
+            Wm = second_key ? 1u : 0u;
+        }
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            bool second_key;
+            const bool hit = pair_hit2(lut, s[j], MODE == 1 ? n[j] & idmask : n[j], second_key);
+            Hm = Hm + Hm + (hit ? 1u : 0u);
+            Wm = Wm + Wm + (second_key ? 1u : 0u);
+        }
+        if (__ballot(Hm != 0u) == 0ull && DIAG != 3 && DIAG != 5) return q_orig;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t sec = MODE == 1 ? n[j] & idmask : n[j];
-            bool second_key;
-            const bool hit = pair_hit2(lut, s[j], sec, second_key);
             idx[j] = kNone;
-            if (__ballot(hit) != 0ull) {
-                const uint32_t ix = lut_index_known(lut, s[j], sec, second_key);
-                idx[j] = hit ? ix : kNone;
+            if (__ballot(((Hm >> j) & 1u) != 0u) != 0ull) {
+                const uint32_t got = lut_index_known(lut, s[j], MODE == 1 ? n[j] & idmask : n[j], ((Wm >> j) & 1u) != 0u);
+                idx[j] = (Hm >> j) & 1u ? got : kNone;
             }
+        }
+        eidx = kNone;
+        if (__ballot(((Hm >> 8) & 1u) != 0u) != 0ull) {
+            const uint32_t got = lut_index_known(lut, ef, es, ((Wm >> 8) & 1u) != 0u);
+            eidx = (Hm >> 8) & 1u ? got : kNone;
         }
     }
     if (DIAG == 3 || DIAG == 5) {                // timing-only build: lookups, no merge
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(idx[j]));
+        asm volatile("" :: "v"(eidx));
         return q_orig;
     }
-    // ... of the matches that reach into the tile from the left: (p1, first token) and (p2, p1); uniform
-    uint32_t in1 = kNone, in2 = kNone;
-    if (pair_test(lut, h.p1, tile_first & idmask)) in1 = (uint32_t)lut_index(lut, h.p1, tile_first & idmask);
-    if (h.p2 != kHole && pair_test(lut, h.p2, h.p1 & idmask)) in2 = (uint32_t)lut_index(lut, h.p2, h.p1 & idmask);
+    const uint32_t in1 = rlane(eidx, 0), in2 = rlane(eidx, 1), out1 = rlane(eidx, 2);
+    {
+        // the last live slot (lane li / 8, slot li % 8) looks at the next tile's first token
+        const uint32_t li = live - 1u;
+        const bool mine = lane == (li >> 3);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j)
+            if ((li & 7u) == j) { n[j] = mine ? h.n1 : n[j]; idx[j] = mine ? out1 : idx[j]; }
+    }
     const uint32_t prev7 = wave_from_prev(idx[7] | (s[7] << 16), in1 | (h.p1 << 16));    // the slot before this lane's first
     const uint32_t prev6 = wave_from_prev(idx[6], in2);                                  // ... and the one before that
     const int lrem = (int)live - (int)(lane * 8u);
@@ -3195,7 +3244,10 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     __shared__ __attribute__((aligned(16))) uint16_t stage_mem[kLutThreads / kWave][kTileSlots];
     uint16_t *stage = stage_mem[threadIdx.x / kWave];
     // tiles are in prefix form and take the short tile function (fused_tile_pf), except for batches with (t,t) members
-    constexpr bool PF = !TT;
+#ifndef MBPE_FUSED_PF
+#define MBPE_FUSED_PF 1
+#endif
+    constexpr bool PF = MBPE_FUSED_PF && !TT;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     uint16_t *dst = ctl->cur ? tok0 : tok1;
     const uint32_t X0 = 256u + ctl->k_done;
@@ -3583,10 +3635,6 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
 // A new token's pairs are plain stores; their argmax bounds are raised once per wave.
 constexpr int kApplyTile = 64;
 constexpr uint32_t kApplyJParts = 16;
-#ifndef MBPE_APPLY_FLIGHT
-#define MBPE_APPLY_FLIGHT 16
-#endif
-constexpr uint32_t kApplyFlight = MBPE_APPLY_FLIGHT;     // decrements (with their old values coming back) in flight per lane
 
 // Inserting runs of neighbouring cells: dense_insert_store writes the cells (new pairs: plain stores) and hands back each
 // lane's packed value; the caller keeps a running maximum per tile and raises the argmax bounds once at the end
@@ -3605,9 +3653,9 @@ __device__ __forceinline__ void dense_raise_bounds(const PairTable &t, unsigned 
         const uint32_t blk0 = rfl(__shfl(blk, (uint32_t)__builtin_ctzll(m), kWave));
         const bool mine = p != 0ull && blk == blk0;
         const unsigned long long pm = wave_max_u64(mine ? p : 0ull);
-        if (lane_id() == 0) {               // (fire and forget: reading the bound first would be a round trip per tile)
-            atomicMax(&t.bmax[blk0], pm);
-            atomicMax(&t.smax[blk0 >> kBlockShift], pm);
+        if (lane_id() == 0) {               // (read first: atomics of thousands of waves on the few super-block bounds would queue)
+            if (pm > t.bmax[blk0]) atomicMax(&t.bmax[blk0], pm);
+            if (pm > t.smax[blk0 >> kBlockShift]) atomicMax(&t.smax[blk0 >> kBlockShift], pm);
         }
         m &= ~__ballot(mine);
     }
@@ -3630,48 +3678,39 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
         if (threadIdx.x < (uint32_t)kApplyTile) keys[threadIdx.x] = j0 + threadIdx.x < n ? bs->key[j0 + threadIdx.x] : 0u;
         // load (and clear) the deltas of ids x0.. and pairs j0..: the rows L_j, R_j of LR are contiguous along x
         const uint32_t pitch = lr_pitch(X0);
-        constexpr uint32_t kRows = kApplyTile / (256 / kWave);        // rows (columns) per wave: 16
-        {
-            // (all of a wave's loads are issued before the first store: the rows are independent, the compiler cannot know)
-            const uint32_t x = x0 + lane;
-            uint32_t vl[kRows], vr[kRows];
-#pragma unroll
-            for (uint32_t u = 0; u < kRows; ++u) {
-                const uint32_t j = j0 + wave + u * (256 / kWave);
-                const bool ok = x < X0 && j < n;
-                const uint32_t *cl = LR + (size_t)(2u * j) * pitch + x;
-                vl[u] = ok ? __builtin_nontemporal_load(cl) : 0u;
-                vr[u] = ok ? __builtin_nontemporal_load(cl + pitch) : 0u;
+        for (uint32_t c = wave; c < (uint32_t)kApplyTile; c += 256 / kWave) {
+            const uint32_t x = x0 + lane, j = j0 + c;
+            uint2 lr = make_uint2(0, 0);
+            if (x < X0 && j < n) {
+                uint32_t *cl = LR + (size_t)(2u * j) * pitch + x, *cr = cl + pitch;
+                lr = make_uint2(*cl, *cr);
+                if (lr.x) *cl = 0;
+                if (lr.y) *cr = 0;
+                if (j >= commit) lr = make_uint2(0, 0);
             }
-#pragma unroll
-            for (uint32_t u = 0; u < kRows; ++u) {
-                const uint32_t c = wave + u * (256 / kWave), j = j0 + c;
-                uint32_t *cl = LR + (size_t)(2u * j) * pitch + x;
-                if (vl[u]) *cl = 0;
-                if (vr[u]) *(cl + pitch) = 0;
-                tile[lane][c] = j < commit ? make_uint2(vl[u], vr[u]) : make_uint2(0, 0);
-            }
+            tile[lane][c] = lr;
         }
         __syncthreads();
         // The decrements return the old value (an absent pair or a negative count is an error worth
-        // knowing about); kApplyFlight of them are in flight per lane before the first one is looked at.
+        // knowing about); four of them are in flight per lane before the first one is looked at.
+        constexpr uint32_t kRows = kApplyTile / (256 / kWave);        // rows (columns) per wave: 16
         uint32_t err = 0, n_new = 0;
         // lanes along j: left neighbours x
         const uint32_t jl = j0 + lane;
         const uint32_t a = keys[lane] >> 16;
         // (new pairs (x, X_j): this lane's column X0 + jl, rows x0 .. x0 + 63 = two rows of tiles)
         unsigned long long accL[2] = {0ull, 0ull};
-        for (uint32_t r0 = 0; r0 < kRows; r0 += kApplyFlight) {
-            uint32_t l[kApplyFlight], old[kApplyFlight];
+        for (uint32_t r0 = 0; r0 < kRows; r0 += 4) {
+            uint32_t l[4], old[4];
 #pragma unroll
-            for (uint32_t u = 0; u < kApplyFlight; ++u) {
+            for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t r = wave + (r0 + u) * (256 / kWave), x = x0 + r;
                 l[u] = tile[r][lane].x;
                 old[u] = kPresent | l[u];
                 if (l[u]) old[u] = atomicAdd(&t.cells[dense_index(t, (x << 16) | a)], 0u - l[u]);
             }
 #pragma unroll
-            for (uint32_t u = 0; u < kApplyFlight; ++u) {
+            for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t r = wave + (r0 + u) * (256 / kWave), x = x0 + r;
                 const unsigned long long p = dense_insert_store(t, l[u] != 0u, dense_index(t, (x << 16) | (X0 + jl)),
                                                                 (x << 16) | (X0 + jl), l[u], n_new);
@@ -3679,7 +3718,7 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
                 accL[rb] = p > accL[rb] ? p : accL[rb];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < kApplyFlight; ++u)
+            for (uint32_t u = 0; u < 4; ++u)
                 err |= !(old[u] & kPresent) ? kErrMissingPair : ((old[u] & ~kPresent) < l[u] ? kErrNegCount : 0u);
         }
 #pragma unroll
@@ -3690,17 +3729,17 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
         // (new pairs (X_j, x): rows X0 + j0 .. + 63 = up to three rows of tiles, this lane's column xr)
         unsigned long long accR[3] = {0ull, 0ull, 0ull};
         const uint32_t Xrow0 = (X0 + j0) >> 5;
-        for (uint32_t c0 = 0; c0 < kRows; c0 += kApplyFlight) {
-            uint32_t rr[kApplyFlight], old[kApplyFlight];
+        for (uint32_t c0 = 0; c0 < kRows; c0 += 4) {
+            uint32_t rr[4], old[4];
 #pragma unroll
-            for (uint32_t u = 0; u < kApplyFlight; ++u) {
+            for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t c = wave + (c0 + u) * (256 / kWave), j = j0 + c;
                 rr[u] = j < n ? tile[lane][c].y : 0u;
                 old[u] = kPresent | rr[u];
                 if (rr[u]) old[u] = atomicAdd(&t.cells[dense_index(t, ((keys[c] & 0xFFFFu) << 16) | xr)], 0u - rr[u]);
             }
 #pragma unroll
-            for (uint32_t u = 0; u < kApplyFlight; ++u) {
+            for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t c = wave + (c0 + u) * (256 / kWave), X = X0 + j0 + c;
                 const unsigned long long p = dense_insert_store(t, rr[u] != 0u, dense_index(t, (X << 16) | xr), (X << 16) | xr,
                                                                 rr[u], n_new);
@@ -3710,7 +3749,7 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
                 else accR[2] = p > accR[2] ? p : accR[2];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < kApplyFlight; ++u)
+            for (uint32_t u = 0; u < 4; ++u)
                 err |= !(old[u] & kPresent) ? kErrMissingPair : ((old[u] & ~kPresent) < rr[u] ? kErrNegCount : 0u);
         }
 #pragma unroll
