@@ -1228,6 +1228,36 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
                 c->stats.merge_launches++;
             }
         }
+        {
+            // Did the table run out of pairs with a count?  best[k - batch .. k] are the pairs of this batch's steps and
+            // of the next one.  Merging a pair that occurs nowhere changes neither the stream nor the table, so every
+            // later choice is that pair again: `first` ends there like the reference's loop (its rebuilt table is empty,
+            // Tokenizer.h:586-588), `lexical` keeps choosing it (PairCountLexicalOrder never erases) -- the rest of this
+            // call's steps are filled in without their passes, as train_steps_batched does.
+            std::vector<unsigned long long> hb(batch + 1);
+            HIPCHK(hipMemcpy(hb.data(), c->best + (c->k - batch), hb.size() * 8, hipMemcpyDeviceToHost));
+            uint32_t z = 0;
+            while (z <= batch && (hb[z] >> 32) != 0) ++z;
+            if (z <= batch) {
+                const uint32_t kz = c->k - batch + z;          // the first step whose pair has count 0
+                if (c->opt_first) {
+                    done += z;
+                    c->k = kz;
+                    c->n_target = kz;
+                } else {
+                    const uint32_t target = std::min<uint64_t>((uint64_t)c->k + (n_steps - done - batch), c->n_target);
+                    if (target > c->k) {
+                        std::vector<unsigned long long> rest(target - c->k, hb[z]);
+                        HIPCHK(hipMemcpy(c->best + c->k + 1, rest.data(), rest.size() * 8, hipMemcpyHostToDevice));
+                    }
+                    done += batch + (target - c->k);
+                    c->k = target;
+                }
+                rc = after_batch(c);
+                if (rc != MBPE_OK) return rc;
+                break;
+            }
+        }
         done += batch;
         rc = after_batch(c);
         if (rc != MBPE_OK) return rc;

@@ -7,6 +7,7 @@
 #define MBPE_HOST_H
 
 #include <cstdint>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -15,6 +16,12 @@ namespace mbpe_host {
 // last error text of the calling thread (returned by mbpe_last_error())
 void set_last_error(const std::string &msg);
 const char *last_error();
+
+// a failed C-ABI call inside the C++ layer: the MBPE_ERR_* code travels with the text
+struct CodedError : std::runtime_error {
+    int code;
+    CodedError(int c, const std::string &msg) : std::runtime_error(msg), code(c) {}
+};
 
 // Tokenizer.h:59-60; nullptr for an unknown encoder name
 const char *split_pattern_for(const std::string &encoder);

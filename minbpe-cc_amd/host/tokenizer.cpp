@@ -226,7 +226,7 @@ std::vector<Token> Tokenizer::encode(const std::string &text, bool verbose, int 
         const int rc = mbpe_encode_chunks(device, reinterpret_cast<const uint8_t *>(buf.data()), buf.size(), off.data(),
                                           off.size() - 1, flat.data(), static_cast<uint32_t>(merges_.size()),
                                           out.data(), out.size(), &n, nullptr);
-        if (rc != MBPE_OK) throw std::runtime_error(mbpe_last_error());
+        if (rc != MBPE_OK) throw mbpe_host::CodedError(rc, mbpe_last_error());       // (the C-ABI hands the code on unchanged)
         out.resize(n);
     } else {
         for (size_t c = 0; c + 1 < off.size(); ++c) {           // internal_encode :370-377 + flatten :713-717
@@ -444,10 +444,12 @@ int mbpe_tok_encode_device(mbpe_tokenizer *t, const uint8_t *text, uint64_t n, i
         if (cap < enc.size()) { mbpe_host::set_last_error("tokens_out too small"); return MBPE_ERR_ARG; }
         memcpy(tokens_out, enc.data(), enc.size() * sizeof(uint32_t));
         return MBPE_OK;
+    } catch (const mbpe_host::CodedError &e) {      // mbpe_encode_chunks failed: its own code (no device, memory, HIP, ids)
+        mbpe_host::set_last_error(e.what());
+        return e.code;
     } catch (const std::exception &e) {
-        const std::string msg = e.what();
-        mbpe_host::set_last_error(msg);
-        return msg.find("no usable HIP device") != std::string::npos ? MBPE_ERR_NO_DEVICE : MBPE_ERR_ARG;
+        mbpe_host::set_last_error(e.what());
+        return MBPE_ERR_ARG;
     }
 }
 

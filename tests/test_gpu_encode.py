@@ -142,3 +142,12 @@ def test_training_with_a_pattern_that_leaves_gaps():
     tok = mbpe.Tokenizer(r"\p{L}+")
     tok.train(data, 400)
     assert tok.merges().tolist() == want_m.tolist()
+
+
+def test_encode_on_a_device_that_does_not_exist_reports_its_own_code():
+    """mbpe_tok_encode_device hands on the code of the failing call (mbpe_encode_chunks), not a guess from the text."""
+    tok = mbpe.Tokenizer("")
+    tok.set_merges(np.array([[97, 98]], dtype=np.uint32))
+    with pytest.raises(mbpe.MbpeError) as e:
+        tok.encode(b"abab", device=99)
+    assert e.value.code == mbpe.ERR_NO_DEVICE

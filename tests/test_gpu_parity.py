@@ -710,3 +710,32 @@ def test_batch_option_changed_after_begin_on_flat_counts(tr):
     finally:
         _defaults(tr)
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
+@pytest.mark.parametrize("mode", ["first", "lexical"])
+def test_one_merge_loop_ends_with_the_table(tr, mode):
+    """The one-merge-per-pass loop (`first` by default, "multi_merge" 0) on a corpus whose pairs run out long before the
+    vocabulary is full: `first` stops where the reference's loop breaks (Tokenizer.h:586-588) and reports only the
+    real merges; `lexical` keeps choosing the last, zero-count pair (PairCountLexicalOrder never erases) without a pass
+    per choice.  Either way no stream pass runs once the best count is 0."""
+    data = np.frombuffer(b"abcabdabcabd" * 40 + b"xyz", dtype=np.uint8)
+    vocab = 256 + 3000
+    want_m, want_c = O.train(data, vocab, mode=O.FIRST if mode == "first" else O.LEXICAL)
+    real = int(np.count_nonzero(want_c))
+    assert 0 < real < 40
+    tr.set_option("multi_merge", 0)
+    tr.set_option("time_kernels", 1)          # (then mbpe_stats.merge_launches counts the stream passes)
+    try:
+        tr.load_corpus(data)
+        tr.set_option("conflict_resolution", 0 if mode == "first" else 1)
+        tr.train_begin(vocab)
+        done = tr.train_steps(vocab - 256)
+        m, c = tr.train_result()
+        st = tr.stats()
+    finally:
+        _defaults(tr)
+        tr.set_option("time_kernels", 0)
+        tr.set_option("conflict_resolution", 1)
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+    assert done == len(want_m)
+    assert st["merge_launches"] <= real + 2 * DEFAULTS["batch"]   # (passes: the real merges and at most a group behind them)
