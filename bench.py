@@ -132,15 +132,21 @@ def cpu_baseline(data, merges, what):
 # What a fused pass cannot go below, from measurements kept under profiles/ (profiles/make_floor_json.py writes the
 # file from a timing-only build of the kernel and from the SQ counters of the shipped one; nothing is hard-coded here):
 #   copy_only_GBps   k_fused_batch with everything but the tile copy compiled out (MBPE_FUSED_DIAG=4)
-#   valu_per_tile    vector instructions the shipped kernel executes per 512-slot tile (SQ_INSTS_VALU / tiles)
+#   valu_per_tile    vector instructions the shipped kernel executes per 512-slot tile (SQ_INSTS_VALU / tiles) in the
+#                    pass that executes most (a 2048-pair batch)
 #   clock_GHz        shader clock during the pass (SQ_BUSY_CYCLES per shader engine / duration)
+#   ladder_ms        the same four passes with timing-only builds: copy, + lookups, all but the count deltas, shipped;
+#                    delta_ps_per_match = (shipped - all but the count deltas) / matches of a pass
+# floor_model.floor_ms is the streaming floor; model_ms = "all but the count deltas" scaled to the pass's tiles + the
+# count deltas of its matches, next to measured_ms.
 FLOOR_FILE = os.path.join("profiles", "r03_fused_floor.json")
-FUSED_LIMITER = ("vector-instruction issue: ~490 vector instructions per 512-slot tile (8 lookup-table tests, next / "
-                 "previous-live-token chains over the holes, carry chains for second tokens and touching matches, tile "
-                 "summaries, ~190 for a dozen matches) keep the SIMDs ~80 % busy at 4 waves per SIMD; the two count-delta "
-                 "atomics per match execute at the memory side meanwhile -- taking them out of the kernel (record log) or "
-                 "processing the matches densely changed neither the instruction count nor the time "
-                 "(profiles/r03_fused_log_ab.md, DESIGN.md section 4)")
+FUSED_LIMITER = ("issue and the count-delta atomics, additively: timing-only builds of the kernel on the same four passes "
+                 "(profiles/r03_fused_diag.log, tools/fused_diag.py) take 3.5 ms to copy the stream, 3.2 ms with the nine "
+                 "lookups per lane on top (hidden under the copy), 4.9 ms with everything but the two count-delta atomics per "
+                 "match and 8.0 ms as shipped: ~60 ps per match that no other work of the wave overlaps (four waves per "
+                 "SIMD, each waits for its atomics to be taken); a pass of a 2048-pair batch (1.3e8 matches) is bound by "
+                 "them.  The vector instructions (~430 per 512-slot tile, SIMDs ~60 % busy) went down with the "
+                 "prefix-form tiles of round 3 (no chains over holes), the time by 3-7 % (DESIGN.md section 4)")
 
 
 def published_workload(device, with_cpu):
@@ -310,11 +316,19 @@ def main():
             tiles = (s1["fused_slots"] - s0["fused_slots"]) / n_fused / 512.0
             stream_ms = pass_bytes / (fl["copy_only_GBps"] * 1e9) * 1e3
             valu_ms = fl["valu_per_tile"] * tiles * 4.0 / (fl["simds"] * fl["clock_GHz"] * 1e9) * 1e3
+            matches = (s0["n_live"] - s1["n_live"]) / max(n_pass, 1)
+            lad = fl.get("ladder_ms") or {}
+            full_tiles = 4294967296.0 / 512.0           # the ladder was measured on passes over 2^32 slots
+            no_delta_ms = lad.get("all_but_count_deltas") * tiles / full_tiles if lad.get("all_but_count_deltas") else None
+            delta_ms = fl["delta_ps_per_match"] * matches * 1e-9 if fl.get("delta_ps_per_match") else None
             floor_model = {"stream_ms": stream_ms, "copy_only_GBps": fl["copy_only_GBps"],
-                           "valu_issue_ms": valu_ms, "valu_per_tile": fl["valu_per_tile"], "tiles_per_launch": tiles,
-                           "clock_GHz": fl["clock_GHz"], "simds": fl["simds"],
-                           "matches_per_launch": (s0["n_live"] - s1["n_live"]) / max(n_pass, 1),
-                           "floor_ms": max(stream_ms, valu_ms), "measured_ms": avg_ms,
+                           "valu_issue_ms": valu_ms, "valu_per_tile_heaviest_pass": fl["valu_per_tile"],
+                           "tiles_per_launch": tiles, "clock_GHz": fl["clock_GHz"], "simds": fl["simds"],
+                           "matches_per_launch": matches,
+                           "ladder_ms": lad, "ladder_matches_per_launch": fl.get("ladder_matches_per_launch"),
+                           "all_but_count_deltas_ms": no_delta_ms, "count_deltas_ms": delta_ms,
+                           "model_ms": (no_delta_ms + delta_ms) if no_delta_ms and delta_ms else None,
+                           "floor_ms": stream_ms, "measured_ms": avg_ms,
                            "sources": FLOOR_FILE + " (" + fl.get("sources", "") + ")"}
     # SURVEY.md 8(d) prices a merge step at 2 B x L read + 2 B x L' written; a pass performs
     # merges_per_pass of them on one read: the same sum divided by the measured time

@@ -2552,7 +2552,11 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                     // a long list tells how dense the counts are here (uniform data: thousands of pairs within
                     // a few hundred counts, where 1/64 of the count would bring back the whole table and send
                     // every selection through the overflow path): extend by what that density needs
-                    const unsigned long long need = (unsigned long long)(want - n_l) + adapt;
+                    // (aiming at a list of want + adapt entries, but never at more than three quarters of what the list
+                    //  holds: an overflowing gather costs two more scans and a worse threshold)
+                    unsigned long long aim = (unsigned long long)want + adapt;
+                    if (aim > 3ull * sel_cap / 4ull) aim = 3ull * sel_cap / 4ull;
+                    const unsigned long long need = aim > (unsigned long long)n_l + 64ull ? aim - n_l : 64ull;
                     spread = (spread * need + n_l - 1) / n_l;
                     if (spread < 1) spread = 1;
                 } else if (spread < 1 + c_lo / 64) {
@@ -3268,13 +3272,19 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
     const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(LR, 0, 0xFFFFFFFCu, 0x00020000);
     const uint32_t adj_pitch = rfl(ctl->adj_pitch);
-    TileIn t0 = tile_issue(tok, sums_rsrc, tile);
-    TileIn t1 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + n_waves));
-    bool v1 = (uint64_t)tile + n_waves < n_tiles;
+    // kDepth tiles are in flight behind the one being worked on (5 registers each)
+#ifndef MBPE_FUSED_DEPTH
+#define MBPE_FUSED_DEPTH 2
+#endif
+    constexpr int kDepth = MBPE_FUSED_DEPTH;
+    TileIn ring[kDepth];
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) ring[d] = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + (uint64_t)d * n_waves));
     const unsigned long long gt_mask = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
     for (;;) {
-        const bool v2 = (uint64_t)tile + 2ull * n_waves < n_tiles;
-        TileIn t2 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + 2ull * n_waves));
+        const bool v1 = (uint64_t)tile + n_waves < n_tiles;
+        const TileIn t_new = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + (uint64_t)kDepth * n_waves));
+        const TileIn t0 = ring[0];
 
         uint4 outq = t0.q;
         bool wrote_sum = false;          // uniform
@@ -3366,8 +3376,9 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
 
         if (!v1) break;
         tile += n_waves;
-        t0 = t1; t1 = t2;
-        v1 = v2;
+#pragma unroll
+        for (int d = 0; d + 1 < kDepth; ++d) ring[d] = ring[d + 1];
+        ring[kDepth - 1] = t_new;
     }
     }
     if (dc_on) dc_flush(dc, LR);

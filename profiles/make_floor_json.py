@@ -19,10 +19,16 @@ ap.add_argument("--trace", required=True)
 ap.add_argument("--slots", type=float, default=4294967296.0)
 a = ap.parse_args()
 copy_ms = None
+ladder = {}
+matches = None
 for line in open(a.diag_log):
-    m = re.match(r"diag 4 .*avg ms ([0-9.]+)", line)
+    m = re.match(r"diag (\d) .*avg ms ([0-9.]+)", line)
     if m:
-        copy_ms = float(m.group(1))
+        ladder[int(m.group(1))] = float(m.group(2))
+    m = re.match(r"diag 0 .*matches per launch ([0-9.]+)", line)
+    if m:
+        matches = float(m.group(1))
+copy_ms = ladder.get(4)
 by = collections.defaultdict(dict)
 for r in csv.DictReader(open(a.counters)):
     if "k_fused_batch" in r["Kernel_Name"]:
@@ -37,6 +43,10 @@ clock = c["SQ_BUSY_CYCLES"] / 32.0 / (dur_ms * 1e-3) / 1e9
 print(json.dumps({
     "copy_only_GBps": 4.0 * a.slots / (copy_ms * 1e-3) / 1e9,
     "copy_only_ms": copy_ms,
+    # the same four passes (sequences 7..10 of the benchmark workload) with timing-only builds of the kernel
+    "ladder_ms": {"copy": ladder.get(4), "copy_lookups": ladder.get(3), "all_but_count_deltas": ladder.get(2), "shipped": ladder.get(0)},
+    "ladder_matches_per_launch": matches,
+    "delta_ps_per_match": (ladder[0] - ladder[2]) * 1e9 / matches if matches and 0 in ladder and 2 in ladder else None,
     "valu_per_tile": c["SQ_INSTS_VALU"] / tiles,
     "valu_per_launch": c["SQ_INSTS_VALU"],
     "salu_per_launch": c.get("SQ_INSTS_SALU"),

@@ -1,5 +1,6 @@
 """Where a fused pass spends its time: the same batch run with timing-only instantiations of k_fused_batch
-(library built with -DMBPE_DIAG: tools/mkvar.sh diag -DMBPE_DIAG; MBPE_LIB=build/libmbpe_diag.so).  Results: profiles/r02_fused_ablation.md."""
+(library built with -DMBPE_DIAG: tools/mkvar.sh diag -DMBPE_DIAG; MBPE_LIB=build/libmbpe_diag.so).  Results: profiles/r0N_fused_diag.log.
+diag 0 = the shipped kernel, 2 = everything but the count deltas, 3 / 5 = load + lookups + store, 4 = load + store."""
 import os, sys, json
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "minbpe-cc_amd", "python"))
@@ -25,4 +26,6 @@ for diag in (0, 2, 3, 5, 4):
         print("diag", diag, "error", e)
     s1 = tr.stats()
     nf = s1["fused_launches"] - s0["fused_launches"]
-    print("diag", diag, "fused launches", nf, "avg ms", (s1["ms_fused_kernel"] - s0["ms_fused_kernel"]) / max(nf, 1), flush=True)
+    print("diag", diag, "fused launches", nf, "avg ms", (s1["ms_fused_kernel"] - s0["ms_fused_kernel"]) / max(nf, 1),
+          "matches per launch", (s0["n_live"] - s1["n_live"]) / max(nf, 1) if diag == 0 else "-",
+          "merges per launch", (s1["n_merges"] - s0["n_merges"]) / max(nf, 1) if diag == 0 else "-", flush=True)
