@@ -3165,29 +3165,40 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
     const uint32_t ABm = Am | Bm;
     if (__ballot(ABm != 0u) == 0ull) return q_orig;
 
+    // The lane of a match's FIRST token counts both of its deltas: (p1, a) -> (p1, X) with the token before it and
+    // (b, n2) -> (X, n2) with the token two slots on -- the next lane's, the next tile's (h.n1, h.n2) where the slots end:
+    // the lane of the second token has nothing to count, and a match across the tile edge is counted by this tile.
+    uint32_t n2_7 = wave_from_next(n[0], h.n2);          // the value two slots after slot 7 (n[0] is already patched)
+    uint32_t n2_patch = kSent;                           // (this lane's slot li % 8 is the last live one: two on is h.n2)
+    if (out1 != kNone) {                                 // uniform, rare: the last live token starts a match
+        const uint32_t li = live - 1u;
+        if (lane == (li >> 3)) n2_patch = li & 7u;
+    }
     uint32_t out[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t self = s[j];
-        uint32_t nv = self;
-        if ((ABm >> j) & 1u) {
-            const uint32_t p1 = j == 0 ? prev7 >> 16 : s[j > 0 ? j - 1 : 0];
-            const uint32_t pj = j == 0 ? (prev7 & 0xFFFFu) : idx[j > 0 ? j - 1 : 0];
-            const uint32_t ppj = j == 0 ? prev6 : j == 1 ? (prev7 & 0xFFFFu) : idx[j > 1 ? j - 2 : 0];
-            if ((Am >> j) & 1u) {            // first token of a match: (p1, a) -> (p1, X)
+        uint32_t nv = ((Bm >> j) & 1u) ? kHole : self;
+        if (__ballot(((Am >> j) & 1u) != 0u) != 0ull) {
+            if ((Am >> j) & 1u) {
+                const uint32_t p1 = j == 0 ? prev7 >> 16 : s[j > 0 ? j - 1 : 0];
+                const uint32_t ppj = j == 0 ? prev6 : j == 1 ? (prev7 & 0xFFFFu) : idx[j > 1 ? j - 2 : 0];
                 const uint32_t ja = idx[j];
-                nv = (X0 + ja) | (n[j] & endbit);
-                if (left_open<MODE>(p1) && DIAG != 2) {
-                    if (ppj != kNone) {      // ... (a', b') (a, b): (b', a) -> (X', X)
-                        atomicAdd(&hdr_adj[ppj * adj_pitch + ja], 1u);
-                        delta_add(lr_idx(pitch, self, ppj, 1), 0xFFFFFFFFu);     // takes back the R count of (a', b')
-                    } else {
-                        delta_add(lr_idx(pitch, p1 & idmask, ja, 0u), 1u);
+                const uint32_t btok = n[j];
+                uint32_t n2 = j < 7 ? n[j < 7 ? j + 1 : 7] : n2_7;
+                n2 = n2_patch == (uint32_t)j ? h.n2 : n2;
+                nv = (X0 + ja) | (btok & endbit);
+                if (DIAG != 2) {
+                    if (left_open<MODE>(p1)) {
+                        if (ppj != kNone) {      // ... (a', b') (a, b): (b', a) -> (X', X)
+                            atomicAdd(&hdr_adj[ppj * adj_pitch + ja], 1u);
+                            delta_add(lr_idx(pitch, self, ppj, 1), 0xFFFFFFFFu);     // takes back the R count of (a', b')
+                        } else {
+                            delta_add(lr_idx(pitch, p1 & idmask, ja, 0u), 1u);
+                        }
                     }
+                    if (right_open<MODE>(btok, n2)) delta_add(lr_idx(pitch, n2 & idmask, ja, 1u), 1u);
                 }
-            } else {                         // second token: (b, n1) -> (X, n1)
-                nv = kHole;
-                if (right_open<MODE>(self, n[j]) && DIAG != 2) delta_add(lr_idx(pitch, n[j] & idmask, pj, 1u), 1u);
             }
         }
         out[j] = nv;
