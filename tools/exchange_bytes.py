@@ -17,6 +17,7 @@ torch.cuda.synchronize()
 tr = mbpe.Trainer(0)
 tr.load_corpus_device(corpus.data_ptr(), n, keep=keep)
 tr.set_option("batch", 1)
+tr.set_option("max_batch", 1024)      # (what a sharded run caps its batches at: the exchange grows with the cap)
 tr.train_begin(vocab)
 hdr = (2 + 8 * 8 + 3) // 4 * 4
 hdrb = 1024 + 1024 * 1024
