@@ -1793,10 +1793,10 @@ struct BatchLutHash {
 #endif
 };
 struct BatchLutMem : BatchLutHash {             // (in LDS, one per workgroup: the hash form, or -- over the same bytes -- the byte form)
-    uint16_t byte_tail[kByteRows * kByteCols > sizeof(BatchLutHash) / 2 ? kByteRows * kByteCols - sizeof(BatchLutHash) / 2 : 1];
+    uint16_t byte_tail[kByteTable && kByteRows * kByteCols > sizeof(BatchLutHash) / 2 ? kByteRows * kByteCols - sizeof(BatchLutHash) / 2 : 1];
     __device__ __forceinline__ uint16_t *byte_tab() { return reinterpret_cast<uint16_t *>(this); }
 };
-static_assert(sizeof(BatchLutMem) >= kByteRows * kByteCols * 2, "the byte table overlays the hash table");
+static_assert(!kByteTable || sizeof(BatchLutMem) >= kByteRows * kByteCols * 2, "the byte table overlays the hash table");
 // The hash of a batch's table is second * mul + first (one v_mad_u32_u24), masked; mul is chosen per batch by the
 // selection among kHashMul so that no bucket needs a third key for as long as possible (BatchState::hash_mul) and
 // reaches the stream kernels in a scalar register.
@@ -1812,7 +1812,7 @@ struct BatchLut {
     bool bytes;                  // uniform: the byte form
     uint32_t idmask;             // 0x7FFF with chunk-end bits in the slots, else 0xFFFF (where the stand-in ids lie)
     __device__ __forceinline__ BatchLut(BatchLutMem *mem, const BatchState *bs, uint32_t idmask_)
-        : m(mem), mul(rfl(bs->hash_mul)), bytes(rfl(bs->byte_lut) != 0u), idmask(idmask_) {}
+        : m(mem), mul(rfl(bs->hash_mul)), bytes(kByteTable && rfl(bs->byte_lut) != 0u), idmask(idmask_) {}
 };
 
 // byte form: the table entry of (first, second); first: any raw slot value, second: a token id (or kHole)
@@ -2409,7 +2409,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         uint32_t alive = (1u << kHashSeeds) - 1u;   // hash multipliers under which every bucket still holds its keys
         // every member so far is a pair of raw bytes (a (t,t) member: its token is): such a batch is looked up in the direct
         // byte x byte table and needs no room in the hash buckets (BatchState::byte_lut)
-        bool all_bytes = byte_table != 0u;
+        bool all_bytes = kByteTable && byte_table != 0u;
         uint32_t tracked = 0, tracked_tt = 0;       // members (and (t,t) members among them) the bucket fills know
         if (tid == 0) bs->tt_index = kNoTT;
         unsigned long long cand_next = n_l ? sp[0] : 0ull;         // (the next candidate is read one step ahead)
@@ -3080,9 +3080,12 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     constexpr uint32_t kNone = 0xFFFFu;          // "this slot starts no match" (batch indices are below kBatchMax)
     const uint32_t pitch = lr_pitch(X0);        // uniform
+    // (timing-only build 6: every XCD counts into rows of its own -- 512 pairs further on per XCD; run it with
+    //  "max_batch" 512 -- to see what the atomics cost when no two XCDs ever touch the same cache line)
+    const uint32_t xcd_off = DIAG == 6 ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) * (2u * 512u * pitch) : 0u;
     auto delta_add = [&](uint32_t idx, uint32_t delta) {
         if (dc_on) dc_add(dc, true, LR, idx, delta);
-        else __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)delta, lr_rsrc, idx << 2, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)delta, lr_rsrc, (idx + xcd_off) << 2, 0, 0);
     };
     uint32_t lane = lane_id();
     asm volatile("" : "+v"(lane));
@@ -4432,6 +4435,7 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
     MBPE_FUSED_DIAG_CASE(3)
     MBPE_FUSED_DIAG_CASE(4)
     MBPE_FUSED_DIAG_CASE(5)
+    MBPE_FUSED_DIAG_CASE(6)
 #undef MBPE_FUSED_DIAG_CASE
 #endif
     MBPE_BY_MODE(endbit, {

@@ -29,6 +29,12 @@ constexpr int kMergeThreads = 256;     // 4 waves per workgroup, each wave walks
 #define MBPE_LUT_THREADS 1024
 #endif
 constexpr int kLutThreads = MBPE_LUT_THREADS;
+// the byte x byte form of a batch's lookup table (137 KB of LDS); 0: every batch goes through the hash table (A/B builds
+// with a small table and several workgroups per CU)
+#ifndef MBPE_BYTE_TABLE
+#define MBPE_BYTE_TABLE 1
+#endif
+constexpr bool kByteTable = MBPE_BYTE_TABLE != 0;
 constexpr int kSlotsPerLane = 8;
 
 // What a tile exposes to its neighbours.  A merge pass reads these (never the

@@ -14,7 +14,9 @@ torch.cuda.synchronize()
 tr = mbpe.Trainer(0)
 tr.load_corpus_device(corpus.data_ptr(), n, keep=keep)
 tr.set_option("time_kernels", 1)
-for diag in (0, 2, 3, 5, 4):
+if os.environ.get("FUSED_DIAG_MAXBATCH"):
+    tr.set_option("max_batch", int(os.environ["FUSED_DIAG_MAXBATCH"]))
+for diag in [int(x) for x in os.environ.get("FUSED_DIAG_LIST", "0,2,3,5,4").split(",")]:
     os.environ.pop("MBPE_FUSED_DIAG", None)
     tr.train_begin(32000)
     tr.train_sequences(6)          # warm-up with the real kernel: a real batch is selected next
