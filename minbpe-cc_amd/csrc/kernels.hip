@@ -2294,8 +2294,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
     // and how many keys every bucket of the kernels' lookup table holds -- under each of the kHashSeeds hash
     // multipliers still in the race (small packed counters)
     __shared__ uint32_t set_first[2048], set_second[2048];
-    constexpr uint32_t kCntFold = kSelCap > 4096u ? 0x1FFFu : 0x7FFFu;      // (a longer candidate list needs the LDS)
-    __shared__ uint8_t cnt_first[kCntFold + 1u], cnt_second[kCntFold + 1u];
+    __shared__ uint32_t g_first[8], g_second[8];      // the same for the 64 candidates of a bulk step (raw bytes only)
     constexpr uint32_t kFillBits = kBucketKeys <= 3 ? 2 : 4, kFillPerWord = 32 / kFillBits;
     __shared__ uint32_t bucket_fill[kHashSeeds][kBuckets / kFillPerWord];
     __shared__ uint16_t acc_ci[kBatchMax];         // list position of every accepted member (written out after the walk)
@@ -2332,10 +2331,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         si[i] = i < n_l ? sel->eidx[i] : 0u;
     }
     for (uint32_t i = tid; i < 2048u; i += kPickThreads) { set_first[i] = 0; set_second[i] = 0; }
-    for (uint32_t i = tid; i < (kCntFold + 1u) / 4u; i += kPickThreads) {
-        reinterpret_cast<uint32_t *>(cnt_first)[i] = 0;
-        reinterpret_cast<uint32_t *>(cnt_second)[i] = 0;
-    }
+    if (tid < 8u) { g_first[tid] = 0; g_second[tid] = 0; }
     for (uint32_t i = tid; i < (uint32_t)kHashSeeds * (kBuckets / kFillPerWord); i += kPickThreads) (&bucket_fill[0][0])[i] = 0;
     __syncthreads();
     // bitonic sort, descending by packed value (unique per pair: a total order)
@@ -2413,7 +2409,46 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         uint32_t tracked = 0, tracked_tt = 0;       // members (and (t,t) members among them) the bucket fills know
         if (tid == 0) bs->tt_index = kNoTT;
         unsigned long long cand_next = n_l ? sp[0] : 0ull;         // (the next candidate is read one step ahead)
+        uint32_t next_bulk = 0;                     // a bulk step is tried again from this list position on
         for (; accepted < limit && ci < n_l; ++ci) {
+            // Bulk step: while every member is a pair of raw bytes (no bucket bookkeeping) the next 64 candidates are
+            // looked at one per lane and accepted together when the one-by-one walk would accept every one of them:
+            // plain byte pairs with a count, none dependent on a member or on another candidate of the 64 (a token that
+            // is first element of one and second of another: tested against bitmaps of the 64, which flags every pair of
+            // candidates that depend on each other), none below the floor of a passed-over candidate.  Anything
+            // else: the walk takes these candidates one by one and tries again 64 positions on.
+            if (all_bytes && !first_mode && ci >= next_bulk && accepted + kWave <= limit && ci + kWave <= n_l) {
+                const unsigned long long gc = sp[ci + tid];
+                const uint32_t gcount = (uint32_t)(gc >> 32), gkey = ~(uint32_t)gc, ga = gkey >> 16, gb = gkey & 0xFFFFu;
+                bool bad = gcount == 0u || ga == gb || ga >= 256u || gb >= 256u || gc < skip_floor;
+                if (!bad) {
+                    bad = (((set_first[gb >> 5] >> (gb & 31u)) | (set_second[ga >> 5] >> (ga & 31u))) & 1u) != 0u;
+                    atomicOr(&g_first[ga >> 5], 1u << (ga & 31u));
+                    atomicOr(&g_second[gb >> 5], 1u << (gb & 31u));
+                }
+                const bool any_bad = __ballot(bad) != 0ull;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: its LDS operations execute in order)
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                bool dep = false;
+                if (!any_bad) dep = (((g_first[gb >> 5] >> (gb & 31u)) | (g_second[ga >> 5] >> (ga & 31u))) & 1u) != 0u;
+                const bool take = !any_bad && __ballot(dep) == 0ull;
+                if (take) {
+                    atomicOr(&set_first[ga >> 5], 1u << (ga & 31u));
+                    atomicOr(&set_second[gb >> 5], 1u << (gb & 31u));
+                    acc_ci[accepted + tid] = (uint16_t)(ci + tid);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (tid < 8u) { g_first[tid] = 0; g_second[tid] = 0; }
+                if (take) {
+                    accepted += kWave;
+                    ci += kWave - 1u;
+                    cand_next = sp[ci + 1u < n_l ? ci + 1u : ci];
+                    continue;
+                }
+                next_bulk = ci + kWave;
+            }
             const unsigned long long cand = cand_next;
             cand_next = sp[ci + 1u < n_l ? ci + 1u : ci];
             const uint32_t count = (uint32_t)(cand >> 32), key = ~(uint32_t)cand;
@@ -2473,7 +2508,12 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                     }
                     ++n_skip;
                     // (it loses occurrences to every member it depends on: red_q16 is the fraction per such member)
-                    const uint32_t n_dep = (uint32_t)cnt_first[b & kCntFold] + cnt_second[a & kCntFold];
+                    uint32_t n_dep = 0;                   // members it depends on: first element b, or second element a
+                    for (uint32_t i = tid; i < accepted; i += kWave) {
+                        const uint32_t mk = ~(uint32_t)sp[acc_ci[i]];
+                        n_dep += ((mk >> 16) == b ? 1u : 0u) + ((mk & 0xFFFFu) == a ? 1u : 0u);
+                    }
+                    n_dep = wave_sum(n_dep);
                     unsigned long long lose = (unsigned long long)n_dep * red_q16;
                     if (lose > 65536ull) lose = 65536ull;
                     const unsigned long long keep = (unsigned long long)count - (((unsigned long long)count * lose) >> 16);
@@ -2495,8 +2535,6 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             if (l0) {
                 atomicOr(&set_first[a >> 5], 1u << (a & 31u));          // (LDS atomics: no read to wait for)
                 atomicOr(&set_second[b >> 5], 1u << (b & 31u));
-                if (cnt_first[a & kCntFold] != 0xFFu) cnt_first[a & kCntFold] += 1;
-                if (cnt_second[b & kCntFold] != 0xFFu) cnt_second[b & kCntFold] += 1;
                 acc_ci[accepted] = (uint16_t)ci;
                 if (tt && n_tt == 0) { bs->tt_index = accepted; bs->tt_token = a; }
             }
