@@ -137,6 +137,30 @@ def test_config4_merge_order_at_checkpoints_1gib(dev):
         assert len(m) == total and C.counts_nonincreasing(c)
 
 
+@pytest.mark.parametrize("chunked", [False, True])
+def test_text_merge_order_at_checkpoints_71mb(dev, chunked):
+    """The same proof on text (shakespeare.txt x 64, 71 MB; whole and under the GPT-4 split pattern, chunk ends as
+    slot bits): frequent pairs (the delta-cache instantiations), batches that go through the hash table, (t,t)
+    members, tiles that lose most of their tokens and stay in prefix form.  At every checkpoint the table equals a
+    recount of the stream, the next merge is the recount's argmax, and every tile holds its tokens in front."""
+    data = np.frombuffer(read_data("shakespeare.txt") * 64, dtype=np.uint8)
+    off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data) if chunked else None
+    vocab = 256 + 6000
+    with mbpe.Trainer(0) as tr:
+        tr.load_corpus(data, off)
+        tr.train_begin(vocab)
+        for at in (0, 3, 40, 400, 1500, 3500, 5900):
+            have = len(tr.train_result()[0])
+            if at > have:
+                assert tr.train_steps(at - have) == at - have
+            r = C.argmax_at_checkpoint(tr, torch, dev)
+            assert r["ok"] and r["merge"] == at, r
+            assert C.tiles_in_prefix_form(tr, torch, dev), at
+        tr.train_steps(vocab - 256)
+        m, c = tr.train_result()
+        assert len(m) == vocab - 256 and C.counts_nonincreasing(c)
+
+
 def test_library_rccl_next_to_torch_distributed(dev):
     """bench.py at N > 1 initialises torch.distributed's NCCL (= RCCL) backend first and the library's own
     communicator (dlopen of librccl.so.1, ncclCommInitRank) second, in the same process.  Both must work
