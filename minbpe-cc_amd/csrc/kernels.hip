@@ -2849,6 +2849,15 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
     if (__ballot(any) != 0ull && lane_id() == 0) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
 }
 
+// (defined with k_fused_batch; WRITE false = count and mark only)
+template <int MODE, int DIAG, bool WRITE, class DC>
+__device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_t s[8], const Halo h,
+                                               uint32_t old_x, uint32_t old_y, uint32_t old_z, const BatchLut &lut,
+                                               uint32_t X0, uint32_t tile, TileSum *sout, uint32_t *hdr_adj, uint32_t *LR,
+                                               DC &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
+                                               __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage,
+                                               uint32_t *chg);
+
 template <int MODE, bool HOT, bool TT, int DIAG = 0>
 __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0, const uint16_t *tok1,
                                                               const TileSum *__restrict__ sin, uint32_t n_tiles,
@@ -2868,7 +2877,8 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     if ((bs->tt_index != kNoTT) != TT) return;      // (see k_fused_batch)
     __shared__ TTInfo ti;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
-    const uint32_t pitch = rfl(lr_pitch(256u + ctl->k_done));
+    const uint32_t ctl_k_done = rfl(ctl->k_done);
+    const uint32_t pitch = rfl(lr_pitch(256u + ctl_k_done));
     const uint32_t adj_pitch = rfl(ctl->adj_pitch);
     if (hot_mismatch<HOT>(bs->packed[0] >> 32, ctl, hot_launched)) return;     // (see k_merge)
     constexpr bool dc_on = HOT;
@@ -2883,6 +2893,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     auto clamp_tile = [&](uint64_t t) { return (uint32_t)(t < n_tiles ? t : last_tile); };
     const __amdgpu_buffer_rsrc_t sums_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(LR, 0, 0xFFFFFFFCu, 0x00020000);
     TileIn t0 = tile_issue(tok, sums_rsrc, tile);
     TileIn t1 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + n_waves));
     bool v1 = (uint64_t)tile + n_waves < n_tiles;
@@ -2907,6 +2918,13 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             } else {
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
+            if constexpr (MBPE_FUSED_PF && !TT && DIAG == 0) {      // tiles are in prefix form: the fused pass's tile function, counting only
+                uint32_t rm_unused = 0;
+                bool ws_unused = false;
+                fused_tile_pf<MODE, 0, false>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
+                                              256u + ctl_k_done, tile, nullptr, hdr_adj, LR, dc, dc_on, rm_unused, ws_unused,
+                                              lr_rsrc, adj_pitch, nullptr, chg);
+            } else {
             if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);
             // first live token of the lanes after this one (exact), then the candidate
             // test: some slot and its next live token form one of the batch pairs
@@ -2930,6 +2948,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             bool work = __ballot(cand) != 0ull || pair_test(lut, h.p1, tile_first & idmask);
             if (DIAG == 2) { asm volatile("" :: "v"((uint32_t)cand)); work = false; }
             if (work) scan_tile_full<MODE, DIAG>(chg, tile, s, h, lut, n_keys, hdr_adj, LR, pitch, dc, dc_on, TT, ti, adj_pitch);
+            }
         }
         if (!v1) break;
         tile += n_waves;
@@ -3108,12 +3127,13 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
 // batch index of the match a slot starts is looked up once per slot (byte table: the entry itself) and handed to the
 // next two slots by register / DPP: a second token counts for the pair of the slot before it, a first token right
 // after a match for the pair two slots back (ADJ).  Same deltas, same new tile, same summary as fused_tile_full.
-template <int MODE, int DIAG = 0, class DC>
+template <int MODE, int DIAG, bool WRITE, class DC>
 __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_t s[8], const Halo h,
                                                uint32_t old_x, uint32_t old_y, uint32_t old_z, const BatchLut &lut,
                                                uint32_t X0, uint32_t tile, TileSum *sout, uint32_t *hdr_adj, uint32_t *LR,
                                                DC &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
-                                               __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage) {
+                                               __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage,
+                                               uint32_t *chg) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     constexpr uint32_t kNone = 0xFFFFu;          // "this slot starts no match" (batch indices are below kBatchMax)
@@ -3244,6 +3264,10 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
         }
         out[j] = nv;
     }
+    if (!WRITE) {                        // the counting pass of a small batch: mark the tile for k_rewrite_marked
+        if (lane == 0) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
+        return q_orig;
+    }
     uint32_t n_out;
     const uint4 qc = tile_compact(out, stage, n_out);
     wave_rm += live - n_out;
@@ -3300,9 +3324,6 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     __shared__ __attribute__((aligned(16))) uint16_t stage_mem[kLutThreads / kWave][kTileSlots];
     uint16_t *stage = stage_mem[threadIdx.x / kWave];
     // tiles are in prefix form and take the short tile function (fused_tile_pf), except for batches with (t,t) members
-#ifndef MBPE_FUSED_PF
-#define MBPE_FUSED_PF 1
-#endif
     constexpr bool PF = MBPE_FUSED_PF && !TT;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     uint16_t *dst = ctl->cur ? tok0 : tok1;
@@ -3357,8 +3378,8 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
             if constexpr (PF) {
-                outq = fused_tile_pf<MODE, DIAG>(t0.q, s, h, old_x, old_y, old_z, lut, X0, tile, sout, hdr_adj, LR, dc, dc_on,
-                                                 wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage);
+                outq = fused_tile_pf<MODE, DIAG, true>(t0.q, s, h, old_x, old_y, old_z, lut, X0, tile, sout, hdr_adj, LR, dc, dc_on,
+                                                       wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage, chg);
             } else {
             uint32_t lf, c_init, tile_first, cj[8];
             unsigned long long m_live;

@@ -35,6 +35,10 @@ constexpr int kLutThreads = MBPE_LUT_THREADS;
 #define MBPE_BYTE_TABLE 1
 #endif
 constexpr bool kByteTable = MBPE_BYTE_TABLE != 0;
+// the stream passes of a batch use the tile function for prefix-form tiles (fused_tile_pf); 0: the chain-walking ones (A/B)
+#ifndef MBPE_FUSED_PF
+#define MBPE_FUSED_PF 1
+#endif
 constexpr int kSlotsPerLane = 8;
 
 // What a tile exposes to its neighbours.  A merge pass reads these (never the
