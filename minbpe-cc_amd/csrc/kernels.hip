@@ -3928,7 +3928,8 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
     uint32_t tile0 = tile_at(i), tile1 = tile_at((uint64_t)i + n_waves), tile2 = tile_at((uint64_t)i + 2ull * n_waves);
     TileIn t0 = tile_issue(tok, sums_rsrc, tile0);
     TileIn t1 = tile_issue(tok, sums_rsrc, tile1);
-    uint32_t wave_rm = 0;
+    uint32_t wave_rm = 0;              // per lane (chain-walking path), summed over the wave at the end
+    uint32_t wave_rm_uniform = 0;      // whole-wave count (prefix-form path)
     for (;;) {
         const bool has_next = (uint64_t)i + n_waves < n_list;
         const uint32_t tile3 = tile_at((uint64_t)i + 3ull * n_waves);
@@ -3947,6 +3948,22 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
         } else {
             h = halo_slow(sin, n_tiles, tile, le, re);
         }
+        if constexpr (MBPE_FUSED_PF && !TT) {
+            // tiles are in prefix form: the fused pass's tile function without the count deltas, stored in place
+            uint32_t rm = 0;
+            bool wrote = false;          // uniform: the tile changed (its new summary is in the side array)
+            DeltaCacheSmall no_dc;       // (never touched: no deltas in this instantiation)
+            const uint4 qn = fused_tile_pf<MODE, 2, true>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut, X0,
+                                                          tile, sout, nullptr, nullptr, no_dc, false, rm, wrote,
+                                                          __amdgpu_buffer_rsrc_t(), 0u, stage, chg);
+            if (wrote) {
+                reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = qn;
+                if (lane == 0 && marks_all) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));    // (the fused pass set no marks)
+            } else if (lane == 0 && !marks_all) {
+                atomicAnd(&chg[tile >> 5], ~(1u << (tile & 31u)));    // marked for a pair that was dropped
+            }
+            wave_rm_uniform += rm;
+        } else {
         if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);
         const Neigh nb = tile_neighbours(s, h);
         bool changed = false, a1 = false, first = true;
@@ -3989,13 +4006,14 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
         } else if (lane == 0 && !marks_all) {
             atomicAnd(&chg[tile >> 5], ~(1u << (tile & 31u)));    // marked for a pair that was dropped
         }
+        }
 
         if (!has_next) break;
         i += n_waves;
         tile0 = tile1; tile1 = tile2; tile2 = tile3;
         t0 = t1; t1 = t2;
     }
-    const uint32_t tr = wave_sum(wave_rm);
+    const uint32_t tr = wave_sum(wave_rm) + wave_rm_uniform;
     if (lane == 0 && tr) atomicAdd(&ctl->rm, tr);
 }
 
