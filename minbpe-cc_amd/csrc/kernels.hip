@@ -2713,7 +2713,7 @@ __device__ __forceinline__ void tt_rename(uint32_t s[8], Halo &h, const TTInfo &
 // nxt[j]: the live token after slot j (kHole: none); tile_first: the tile's first live token.
 template <int MODE>
 __device__ __forceinline__ bool tt_needed(const uint32_t s[8], const uint32_t nxt[8], const Halo &h,
-                                          uint32_t tile_first, const TTInfo &ti) {
+                                          uint32_t tile_first, const TTInfo &ti, uint32_t live_mask = 0xFFu) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     auto member = [&](uint32_t v) -> bool {
         const uint32_t id = v & idmask;
@@ -2722,6 +2722,7 @@ __device__ __forceinline__ bool tt_needed(const uint32_t s[8], const uint32_t nx
     uint32_t eqm = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) eqm |= (((s[j] ^ nxt[j]) & idmask) == 0u ? 1u : 0u) << j;     // (a hole has no token's id)
+    eqm &= live_mask;            // (prefix-form callers pass the next SLOT: a hole is followed by a hole)
     bool need = false;
     if (__ballot(eqm != 0u) != 0ull) {
 #pragma unroll
@@ -2850,13 +2851,13 @@ __device__ __forceinline__ void scan_tile_full(uint32_t *chg, uint32_t tile, con
 }
 
 // (defined with k_fused_batch; WRITE false = count and mark only)
-template <int MODE, int DIAG, bool WRITE, class DC>
+template <int MODE, int DIAG, bool WRITE, bool TT, class DC>
 __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_t s[8], const Halo h,
                                                uint32_t old_x, uint32_t old_y, uint32_t old_z, const BatchLut &lut,
                                                uint32_t X0, uint32_t tile, TileSum *sout, uint32_t *hdr_adj, uint32_t *LR,
                                                DC &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
                                                __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage,
-                                               uint32_t *chg);
+                                               uint32_t *chg, bool renamed, TTInfo *ti);
 
 template <int MODE, bool HOT, bool TT, int DIAG = 0>
 __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0, const uint16_t *tok1,
@@ -2921,9 +2922,9 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             if constexpr (MBPE_FUSED_PF && !TT && DIAG == 0) {      // tiles are in prefix form: the fused pass's tile function, counting only
                 uint32_t rm_unused = 0;
                 bool ws_unused = false;
-                fused_tile_pf<MODE, 0, false>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
-                                              256u + ctl_k_done, tile, nullptr, hdr_adj, LR, dc, dc_on, rm_unused, ws_unused,
-                                              lr_rsrc, adj_pitch, nullptr, chg);
+                fused_tile_pf<MODE, 0, false, false>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
+                                                     256u + ctl_k_done, tile, nullptr, hdr_adj, LR, dc, dc_on, rm_unused, ws_unused,
+                                                     lr_rsrc, adj_pitch, nullptr, chg, false, nullptr);
             } else {
             if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);
             // first live token of the lanes after this one (exact), then the candidate
@@ -3127,13 +3128,13 @@ __device__ __forceinline__ uint4 fused_tile_full(const uint4 q_orig, bool tt_on,
 // batch index of the match a slot starts is looked up once per slot (byte table: the entry itself) and handed to the
 // next two slots by register / DPP: a second token counts for the pair of the slot before it, a first token right
 // after a match for the pair two slots back (ADJ).  Same deltas, same new tile, same summary as fused_tile_full.
-template <int MODE, int DIAG, bool WRITE, class DC>
+template <int MODE, int DIAG, bool WRITE, bool TT, class DC>
 __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_t s[8], const Halo h,
                                                uint32_t old_x, uint32_t old_y, uint32_t old_z, const BatchLut &lut,
                                                uint32_t X0, uint32_t tile, TileSum *sout, uint32_t *hdr_adj, uint32_t *LR,
                                                DC &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
                                                __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage,
-                                               uint32_t *chg) {
+                                               uint32_t *chg, bool renamed, TTInfo *ti) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     constexpr uint32_t kNone = 0xFFFFu;          // "this slot starts no match" (batch indices are below kBatchMax)
@@ -3148,7 +3149,15 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
     uint32_t lane = lane_id();
     asm volatile("" : "+v"(lane));
     const uint32_t live = old_z & 0xFFFFu;       // uniform, >= 1
-    const uint32_t tile_first = old_x & 0xFFFFu, tile_last = old_y >> 16;
+    uint32_t tile_first = old_x & 0xFFFFu, tile_last = old_y >> 16;
+    if (TT && renamed) {                 // (uniform, rare: s[] and h hold stand-in ids where tt_rename put them)
+        const uint32_t li = live - 1u;
+        uint32_t sl = s[0];
+#pragma unroll
+        for (uint32_t j = 1; j < 8; ++j) sl = (li & 7u) == j ? s[j] : sl;
+        tile_first = rlane(s[0], 0);
+        tile_last = rlane(sl, li >> 3);
+    }
     // the value after every slot (after the last live slot: a hole, or the next tile's first token when the tile is full)
     uint32_t n[8];
 #pragma unroll
@@ -3161,8 +3170,8 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
     uint32_t idx[8], eidx;
     if (lut.bytes) {             // (uniform) the byte table: the entry is the index
 #pragma unroll
-        for (int j = 0; j < 8; ++j) idx[j] = byte_entry<false>(lut, s[j], MODE == 1 ? n[j] & idmask : n[j], idmask);
-        eidx = byte_entry<false>(lut, ef, es, idmask);
+        for (int j = 0; j < 8; ++j) idx[j] = byte_entry<TT>(lut, s[j], MODE == 1 ? n[j] & idmask : n[j], idmask);
+        eidx = byte_entry<TT>(lut, ef, es, idmask);
         // nearly every tile of a small batch: no match anywhere (indices are 16-bit: all kNone iff their AND is)
         const uint32_t all = idx[0] & idx[1] & idx[2] & idx[3] & idx[4] & idx[5] & idx[6] & idx[7] & eidx;
         if (__ballot(all != kNone) == 0ull && DIAG != 3 && DIAG != 5) return q_orig;
@@ -3249,6 +3258,8 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
                 uint32_t n2 = j < 7 ? n[j < 7 ? j + 1 : 7] : n2_7;
                 n2 = n2_patch == (uint32_t)j ? h.n2 : n2;
                 nv = (X0 + ja) | (btok & endbit);
+                if (TT && renamed && (btok & idmask) >= idmask - (uint32_t)kTTMax)       // a match of a (t,t) member: count it
+                    atomicAdd(&ti->cnt[idmask - 1u - (btok & idmask)], 1u);
                 if (DIAG != 2) {
                     if (left_open<MODE>(p1)) {
                         if (ppj != kNone) {      // ... (a', b') (a, b): (b', a) -> (X', X)
@@ -3263,6 +3274,12 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
             }
         }
         out[j] = nv;
+    }
+    if (TT && renamed) {                 // (every renamed token was the second token of a match; be safe)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (out[j] != kHole && (out[j] & idmask) >= idmask - (uint32_t)kTTMax)
+                out[j] = ti->tok[idmask - 1u - (out[j] & idmask)] | (out[j] & endbit);
     }
     if (!WRITE) {                        // the counting pass of a small batch: mark the tile for k_rewrite_marked
         if (lane == 0) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));
@@ -3323,8 +3340,8 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     __shared__ TTInfo ti;
     __shared__ __attribute__((aligned(16))) uint16_t stage_mem[kLutThreads / kWave][kTileSlots];
     uint16_t *stage = stage_mem[threadIdx.x / kWave];
-    // tiles are in prefix form and take the short tile function (fused_tile_pf), except for batches with (t,t) members
-    constexpr bool PF = MBPE_FUSED_PF && !TT;
+    // tiles are in prefix form and take the short tile function (fused_tile_pf); (t,t) members: renamed first where needed
+    constexpr bool PF = MBPE_FUSED_PF != 0;
     const uint16_t *tok = ctl->cur ? tok1 : tok0;
     uint16_t *dst = ctl->cur ? tok0 : tok1;
     const uint32_t X0 = 256u + ctl->k_done;
@@ -3378,8 +3395,27 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
             if constexpr (PF) {
-                outq = fused_tile_pf<MODE, DIAG, true>(t0.q, s, h, old_x, old_y, old_z, lut, X0, tile, sout, hdr_adj, LR, dc, dc_on,
-                                                       wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage, chg);
+                bool renamed = false;    // uniform: tt_rename ran on this tile (only then can stand-in ids occur in it)
+                if constexpr (TT) {
+                    // (t,t) members: does any live token equal its successor and belong to one?  (nearly never)
+                    uint32_t nx[8];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) nx[j] = s[j + 1];
+                    nx[7] = wave_from_next(s[0], h.n1);
+                    const uint32_t li = (old_z & 0xFFFFu) - 1u;
+                    const bool mine = lane == (li >> 3);
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j)
+                        if ((li & 7u) == j) nx[j] = mine ? h.n1 : nx[j];
+                    const int lrem = (int)(old_z & 0xFFFFu) - (int)(lane * 8u);
+                    const uint32_t lm = lrem >= 8 ? 0xFFu : lrem <= 0 ? 0u : (1u << lrem) - 1u;
+                    if (tt_needed<MODE>(s, nx, h, old_x & 0xFFFFu, ti, lm)) {
+                        tt_rename<MODE>(s, h, ti, run_in[tile]);
+                        renamed = true;
+                    }
+                }
+                outq = fused_tile_pf<MODE, DIAG, true, TT>(t0.q, s, h, old_x, old_y, old_z, lut, X0, tile, sout, hdr_adj, LR, dc,
+                                                           dc_on, wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage, chg, renamed, &ti);
             } else {
             uint32_t lf, c_init, tile_first, cj[8];
             unsigned long long m_live;
@@ -3953,9 +3989,9 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
             uint32_t rm = 0;
             bool wrote = false;          // uniform: the tile changed (its new summary is in the side array)
             DeltaCacheSmall no_dc;       // (never touched: no deltas in this instantiation)
-            const uint4 qn = fused_tile_pf<MODE, 2, true>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut, X0,
-                                                          tile, sout, nullptr, nullptr, no_dc, false, rm, wrote,
-                                                          __amdgpu_buffer_rsrc_t(), 0u, stage, chg);
+            const uint4 qn = fused_tile_pf<MODE, 2, true, false>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
+                                                                 X0, tile, sout, nullptr, nullptr, no_dc, false, rm, wrote,
+                                                                 __amdgpu_buffer_rsrc_t(), 0u, stage, chg, false, nullptr);
             if (wrote) {
                 reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = qn;
                 if (lane == 0 && marks_all) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));    // (the fused pass set no marks)
