@@ -1873,7 +1873,9 @@ __device__ __forceinline__ void tt_flush(TTInfo &ti, uint32_t *hdr_m) {
     if (threadIdx.x < (uint32_t)kTTMax && ti.cnt[threadIdx.x]) atomicAdd(&hdr_m[ti.pair[threadIdx.x]], ti.cnt[threadIdx.x]);
 }
 
-__device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys, uint32_t fake) {
+constexpr uint32_t kTTMark = 0xFFFEu;      // byte table, cell (t, t) of a (t,t) member: "two of them side by side: rename first"
+__device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, uint32_t n_keys, uint32_t fake,
+                                          bool tt_marks = false) {
     if (lut.bytes) {
         uint32_t *tw = reinterpret_cast<uint32_t *>(lut.m->byte_tab());
         for (uint32_t i = threadIdx.x; i < (kByteRows * kByteCols + 1u) / 2u; i += blockDim.x) tw[i] = 0xFFFFFFFFu;
@@ -1890,7 +1892,12 @@ __device__ __forceinline__ void lut_build(BatchLut &lut, const BatchState *bs, u
             uint32_t n_tt = 0;
             for (uint32_t j = bs->tt_index; j < n_keys && n_tt < (uint32_t)kTTMax; ++j) {
                 const uint32_t key = bs->key[j];
-                if ((key >> 16) == (key & 0xFFFFu)) tab[(key >> 16) * kByteCols + 256u + n_tt++] = (uint16_t)j;
+                if ((key >> 16) == (key & 0xFFFFu)) {
+                    tab[(key >> 16) * kByteCols + 256u + n_tt++] = (uint16_t)j;
+                    // (only the fused pass on prefix-form tiles asks for it: there the lookup of (slot, next slot) that
+                    //  every slot does anyway tells whether the tile holds a run of a member's token -- no separate test)
+                    if (tt_marks) tab[(key >> 16) * kByteCols + (key >> 16)] = (uint16_t)kTTMark;
+                }
             }
         }
         __syncthreads();
@@ -2857,7 +2864,7 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
                                                uint32_t X0, uint32_t tile, TileSum *sout, uint32_t *hdr_adj, uint32_t *LR,
                                                DC &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
                                                __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage,
-                                               uint32_t *chg, bool renamed, TTInfo *ti);
+                                               uint32_t *chg, bool renamed, TTInfo *ti, bool &need_rename);
 
 template <int MODE, bool HOT, bool TT, int DIAG = 0>
 __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0, const uint16_t *tok1,
@@ -2924,7 +2931,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
                 bool ws_unused = false;
                 fused_tile_pf<MODE, 0, false, false>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
                                                      256u + ctl_k_done, tile, nullptr, hdr_adj, LR, dc, dc_on, rm_unused, ws_unused,
-                                                     lr_rsrc, adj_pitch, nullptr, chg, false, nullptr);
+                                                     lr_rsrc, adj_pitch, nullptr, chg, false, nullptr, ws_unused);
             } else {
             if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);
             // first live token of the lanes after this one (exact), then the candidate
@@ -3134,7 +3141,7 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
                                                uint32_t X0, uint32_t tile, TileSum *sout, uint32_t *hdr_adj, uint32_t *LR,
                                                DC &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
                                                __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage,
-                                               uint32_t *chg, bool renamed, TTInfo *ti) {
+                                               uint32_t *chg, bool renamed, TTInfo *ti, bool &need_rename) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     constexpr uint32_t kNone = 0xFFFFu;          // "this slot starts no match" (batch indices are below kBatchMax)
@@ -3165,8 +3172,9 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
     n[7] = wave_from_next(s[0], h.n1);
     // The batch index of the match every slot starts (kNone: none) -- and of the three matches across the tile's edges,
     // which lanes 0, 1, 2 look up in a ninth read: (p1, first token), (p2, p1), (last token, n1).
-    const uint32_t ef = lane == 0 ? h.p1 : lane == 1 ? h.p2 : lane == 2 ? tile_last : kHole;
-    const uint32_t es = (lane == 0 ? tile_first : lane == 1 ? h.p1 : h.n1) & idmask;
+    // ((t,t) members, byte table: lane 3 looks up (n1, n2) as well -- only for the marker of "a run of a member's token")
+    const uint32_t ef = lane == 0 ? h.p1 : lane == 1 ? h.p2 : lane == 2 ? tile_last : (TT && lane == 3) ? h.n1 : kHole;
+    const uint32_t es = (lane == 0 ? tile_first : lane == 1 ? h.p1 : (TT && lane == 3) ? h.n2 : h.n1) & idmask;
     uint32_t idx[8], eidx;
     if (lut.bytes) {             // (uniform) the byte table: the entry is the index
 #pragma unroll
@@ -3175,11 +3183,25 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
         // nearly every tile of a small batch: no match anywhere (indices are 16-bit: all kNone iff their AND is)
         const uint32_t all = idx[0] & idx[1] & idx[2] & idx[3] & idx[4] & idx[5] & idx[6] & idx[7] & eidx;
         if (__ballot(all != kNone) == 0ull && DIAG != 3 && DIAG != 5) return q_orig;
+        if (TT) {
+            // a run of a (t,t) member's token somewhere in or around the tile: the caller renames (tt_rename) and comes
+            // back; afterwards no two of them are side by side, a marker that still shows up is "no match"
+            bool mark = eidx == kTTMark;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mark = mark || idx[j] == kTTMark;
+            if (__ballot(mark) != 0ull) {
+                if (!renamed) { need_rename = true; return q_orig; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) idx[j] = idx[j] == kTTMark ? kNone : idx[j];
+                eidx = eidx == kTTMark ? kNone : eidx;
+            }
+            eidx = lane == 3 ? kNone : eidx;         // (lane 3's lookup was only there for the marker)
+        }
     } else {                     // the hash table: nine bucket reads, then the index words of the slots that hit
         uint32_t Hm = 0, Wm = 0;         // bit j: slot j (8: the edge lookup) starts a match / ... under its bucket's second key
         {
             bool second_key;
-            const bool hit = pair_hit2(lut, ef, es, second_key);
+            const bool hit = pair_hit2(lut, ef, es, second_key) && !(TT && lane == 3);
             Hm = hit ? 1u : 0u;
             Wm = second_key ? 1u : 0u;
         }
@@ -3349,7 +3371,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     constexpr bool dc_on = HOT;
     if (dc_on) dc_init(dc);
     BatchLut lut(&lut_mem, bs, idmask);
-    lut_build(lut, bs, n_keys, idmask - 1u);
+    lut_build(lut, bs, n_keys, idmask - 1u, TT && MBPE_FUSED_PF);
     if (TT) tt_build(ti, bs, n_keys, idmask - 1u);
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->marks_all = 1;
     uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave);
@@ -3396,8 +3418,10 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
             }
             if constexpr (PF) {
                 bool renamed = false;    // uniform: tt_rename ran on this tile (only then can stand-in ids occur in it)
-                if constexpr (TT) {
-                    // (t,t) members: does any live token equal its successor and belong to one?  (nearly never)
+                bool need_rename = false;
+                if (TT && !lut.bytes) {
+                    // (t,t) members, hash table: does any live token equal its successor and belong to one?  (nearly
+                    // never; with the byte table the slots' own lookups tell: kTTMark)
                     uint32_t nx[8];
 #pragma unroll
                     for (int j = 0; j < 7; ++j) nx[j] = s[j + 1];
@@ -3415,7 +3439,14 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                     }
                 }
                 outq = fused_tile_pf<MODE, DIAG, true, TT>(t0.q, s, h, old_x, old_y, old_z, lut, X0, tile, sout, hdr_adj, LR, dc,
-                                                           dc_on, wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage, chg, renamed, &ti);
+                                                           dc_on, wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage, chg, renamed, &ti,
+                                                           need_rename);
+                if (TT && need_rename) {             // (uniform, rare)
+                    tt_rename<MODE>(s, h, ti, run_in[tile]);
+                    outq = fused_tile_pf<MODE, DIAG, true, TT>(t0.q, s, h, old_x, old_y, old_z, lut, X0, tile, sout, hdr_adj, LR,
+                                                               dc, dc_on, wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage, chg, true,
+                                                               &ti, need_rename);
+                }
             } else {
             uint32_t lf, c_init, tile_first, cj[8];
             unsigned long long m_live;
@@ -3991,7 +4022,7 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
             DeltaCacheSmall no_dc;       // (never touched: no deltas in this instantiation)
             const uint4 qn = fused_tile_pf<MODE, 2, true, false>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
                                                                  X0, tile, sout, nullptr, nullptr, no_dc, false, rm, wrote,
-                                                                 __amdgpu_buffer_rsrc_t(), 0u, stage, chg, false, nullptr);
+                                                                 __amdgpu_buffer_rsrc_t(), 0u, stage, chg, false, nullptr, wrote);
             if (wrote) {
                 reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = qn;
                 if (lane == 0 && marks_all) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));    // (the fused pass set no marks)
