@@ -3786,6 +3786,13 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
 // A new token's pairs are plain stores; their argmax bounds are raised once per wave.
 constexpr int kApplyTile = 64;
 constexpr uint32_t kApplyJParts = 16;
+#ifndef MBPE_APPLY_BOUNDS
+#define MBPE_APPLY_BOUNDS 0
+#endif
+#ifndef MBPE_APPLY_FLIGHT
+#define MBPE_APPLY_FLIGHT 4
+#endif
+constexpr uint32_t kApplyFlight = MBPE_APPLY_FLIGHT;     // decrements (their old values come back) in flight per lane
 
 // Inserting runs of neighbouring cells: dense_insert_store writes the cells (new pairs: plain stores) and hands back each
 // lane's packed value; the caller keeps a running maximum per tile and raises the argmax bounds once at the end
@@ -3797,17 +3804,35 @@ __device__ __forceinline__ unsigned long long dense_insert_store(const PairTable
     n_new += (uint32_t)__popcll(__ballot(active));
     return active ? pack_best((int32_t)count, key) : 0ull;
 }
-__device__ __forceinline__ void dense_raise_bounds(const PairTable &t, unsigned long long p, uint32_t blk) {
-    // p: this lane's maximum (0: none) among the cells it inserted into tile blk; one bound update per tile touched
+// The bounds a wave has to raise are collected first -- (tile, maximum) pairs in a small per-wave list in LDS -- and
+// raised together at the end of the step, one lane per pair: ONE round trip for "is the bound lower?" instead of one
+// per tile (a dozen dependent loads per step were a quarter of this kernel's time).
+constexpr uint32_t kRaiseMax = 16;
+struct RaiseList { unsigned long long pm[kRaiseMax]; uint32_t blk[kRaiseMax]; };
+__device__ __forceinline__ void dense_raise_flush(const PairTable &t, RaiseList &rl, uint32_t &n) {
+    const uint32_t lane = lane_id();
+    if (lane < n) {
+        const unsigned long long pm = rl.pm[lane];
+        const uint32_t blk0 = rl.blk[lane];
+        if (pm > t.bmax[blk0]) atomicMax(&t.bmax[blk0], pm);
+        if (pm > t.smax[blk0 >> kBlockShift]) atomicMax(&t.smax[blk0 >> kBlockShift], pm);
+    }
+    n = 0;
+}
+__device__ __forceinline__ void dense_raise_bounds(const PairTable &t, unsigned long long p, uint32_t blk, RaiseList &rl,
+                                                   uint32_t &n) {
+    // p: this lane's maximum (0: none) among the cells it inserted into tile blk; one list entry per tile touched
+#ifdef MBPE_APPLY_NORAISE
+    return;                      // (timing-only build)
+#endif
     unsigned long long m = __ballot(p != 0ull);
     while (m) {
         const uint32_t blk0 = rfl(__shfl(blk, (uint32_t)__builtin_ctzll(m), kWave));
         const bool mine = p != 0ull && blk == blk0;
         const unsigned long long pm = wave_max_u64(mine ? p : 0ull);
-        if (lane_id() == 0) {               // (read first: atomics of thousands of waves on the few super-block bounds would queue)
-            if (pm > t.bmax[blk0]) atomicMax(&t.bmax[blk0], pm);
-            if (pm > t.smax[blk0 >> kBlockShift]) atomicMax(&t.smax[blk0 >> kBlockShift], pm);
-        }
+        if (n == kRaiseMax) dense_raise_flush(t, rl, n);          // (uniform; does not happen with 64 x 64 steps)
+        if (lane_id() == 0) { rl.pm[n] = pm; rl.blk[n] = blk0; }
+        ++n;
         m &= ~__ballot(mine);
     }
 }
@@ -3816,6 +3841,8 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
                                                            uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR) {
     __shared__ uint2 tile[kApplyTile][kApplyTile + 1];
     __shared__ uint32_t keys[kApplyTile];           // bs->key[j0 ..]
+    __shared__ RaiseList raise[256 / kWave];
+    uint32_t n_raise = 0;                           // uniform per wave
     const uint32_t n = ctl->batch_n;
     if (n < 2) return;
     const uint32_t commit = ctl->commit_n;
@@ -3851,17 +3878,21 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
         const uint32_t a = keys[lane] >> 16;
         // (new pairs (x, X_j): this lane's column X0 + jl, rows x0 .. x0 + 63 = two rows of tiles)
         unsigned long long accL[2] = {0ull, 0ull};
-        for (uint32_t r0 = 0; r0 < kRows; r0 += 4) {
-            uint32_t l[4], old[4];
+        for (uint32_t r0 = 0; r0 < kRows; r0 += kApplyFlight) {
+            uint32_t l[kApplyFlight], old[kApplyFlight];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kApplyFlight; ++u) {
                 const uint32_t r = wave + (r0 + u) * (256 / kWave), x = x0 + r;
                 l[u] = tile[r][lane].x;
                 old[u] = kPresent | l[u];
+#ifdef MBPE_APPLY_NORETURN
+                if (l[u]) atomicAdd(&t.cells[dense_index(t, (x << 16) | a)], 0u - l[u]);
+#else
                 if (l[u]) old[u] = atomicAdd(&t.cells[dense_index(t, (x << 16) | a)], 0u - l[u]);
+#endif
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kApplyFlight; ++u) {
                 const uint32_t r = wave + (r0 + u) * (256 / kWave), x = x0 + r;
                 const unsigned long long p = dense_insert_store(t, l[u] != 0u, dense_index(t, (x << 16) | (X0 + jl)),
                                                                 (x << 16) | (X0 + jl), l[u], n_new);
@@ -3869,28 +3900,32 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
                 accL[rb] = p > accL[rb] ? p : accL[rb];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u)
+            for (uint32_t u = 0; u < kApplyFlight; ++u)
                 err |= !(old[u] & kPresent) ? kErrMissingPair : ((old[u] & ~kPresent) < l[u] ? kErrNegCount : 0u);
         }
 #pragma unroll
         for (uint32_t rb = 0; rb < 2; ++rb)
-            dense_raise_bounds(t, accL[rb], dense_index(t, ((x0 + 32u * rb) << 16) | (X0 + jl)) >> kBlockShift);
+            dense_raise_bounds(t, accL[rb], dense_index(t, ((x0 + 32u * rb) << 16) | (X0 + jl)) >> kBlockShift, raise[wave], n_raise);
         // lanes along x: right neighbours x
         const uint32_t xr = x0 + lane;
         // (new pairs (X_j, x): rows X0 + j0 .. + 63 = up to three rows of tiles, this lane's column xr)
         unsigned long long accR[3] = {0ull, 0ull, 0ull};
         const uint32_t Xrow0 = (X0 + j0) >> 5;
-        for (uint32_t c0 = 0; c0 < kRows; c0 += 4) {
-            uint32_t rr[4], old[4];
+        for (uint32_t c0 = 0; c0 < kRows; c0 += kApplyFlight) {
+            uint32_t rr[kApplyFlight], old[kApplyFlight];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kApplyFlight; ++u) {
                 const uint32_t c = wave + (c0 + u) * (256 / kWave), j = j0 + c;
                 rr[u] = j < n ? tile[lane][c].y : 0u;
                 old[u] = kPresent | rr[u];
+#ifdef MBPE_APPLY_NORETURN
+                if (rr[u]) atomicAdd(&t.cells[dense_index(t, ((keys[c] & 0xFFFFu) << 16) | xr)], 0u - rr[u]);
+#else
                 if (rr[u]) old[u] = atomicAdd(&t.cells[dense_index(t, ((keys[c] & 0xFFFFu) << 16) | xr)], 0u - rr[u]);
+#endif
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
+            for (uint32_t u = 0; u < kApplyFlight; ++u) {
                 const uint32_t c = wave + (c0 + u) * (256 / kWave), X = X0 + j0 + c;
                 const unsigned long long p = dense_insert_store(t, rr[u] != 0u, dense_index(t, (X << 16) | xr), (X << 16) | xr,
                                                                 rr[u], n_new);
@@ -3900,12 +3935,13 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
                 else accR[2] = p > accR[2] ? p : accR[2];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u)
+            for (uint32_t u = 0; u < kApplyFlight; ++u)
                 err |= !(old[u] & kPresent) ? kErrMissingPair : ((old[u] & ~kPresent) < rr[u] ? kErrNegCount : 0u);
         }
 #pragma unroll
         for (uint32_t rb = 0; rb < 3; ++rb)
-            dense_raise_bounds(t, accR[rb], dense_index(t, (((Xrow0 + rb) << 5) << 16) | xr) >> kBlockShift);
+            dense_raise_bounds(t, accR[rb], dense_index(t, (((Xrow0 + rb) << 5) << 16) | xr) >> kBlockShift, raise[wave], n_raise);
+        dense_raise_flush(t, raise[wave], n_raise);
         if (err) atomicOr(&ctl->err, err);
         if (lane == 0 && n_new) atomicAdd(&ctl->n_entries, n_new);
     }
