@@ -2926,12 +2926,13 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
             } else {
                 h = halo_slow(sin, n_tiles, tile, le, re);
             }
-            if constexpr (MBPE_FUSED_PF && !TT && DIAG == 0) {      // tiles are in prefix form: the fused pass's tile function, counting only
+            if constexpr (MBPE_FUSED_PF && DIAG == 0) {      // tiles are in prefix form: the fused pass's tile function, counting only
                 uint32_t rm_unused = 0;
-                bool ws_unused = false;
-                fused_tile_pf<MODE, 0, false, false>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
-                                                     256u + ctl_k_done, tile, nullptr, hdr_adj, LR, dc, dc_on, rm_unused, ws_unused,
-                                                     lr_rsrc, adj_pitch, nullptr, chg, false, nullptr, ws_unused);
+                bool ws_unused = false, no_rename = false;
+                if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);      // ((t,t) members: every tile, as the chain-walking path did)
+                fused_tile_pf<MODE, 0, false, TT>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
+                                                  256u + ctl_k_done, tile, nullptr, hdr_adj, LR, dc, dc_on, rm_unused, ws_unused,
+                                                  lr_rsrc, adj_pitch, nullptr, chg, TT, &ti, no_rename);
             } else {
             if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);
             // first live token of the lanes after this one (exact), then the candidate
@@ -4051,14 +4052,17 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
         } else {
             h = halo_slow(sin, n_tiles, tile, le, re);
         }
-        if constexpr (MBPE_FUSED_PF && !TT) {
+        if constexpr (MBPE_FUSED_PF != 0) {
             // tiles are in prefix form: the fused pass's tile function without the count deltas, stored in place
+            // ((t,t) members: every tile renamed first, as the chain-walking path did)
             uint32_t rm = 0;
             bool wrote = false;          // uniform: the tile changed (its new summary is in the side array)
+            bool no_rename = false;
             DeltaCacheSmall no_dc;       // (never touched: no deltas in this instantiation)
-            const uint4 qn = fused_tile_pf<MODE, 2, true, false>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
-                                                                 X0, tile, sout, nullptr, nullptr, no_dc, false, rm, wrote,
-                                                                 __amdgpu_buffer_rsrc_t(), 0u, stage, chg, false, nullptr, wrote);
+            if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);
+            const uint4 qn = fused_tile_pf<MODE, 2, true, TT>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
+                                                              X0, tile, sout, nullptr, nullptr, no_dc, false, rm, wrote,
+                                                              __amdgpu_buffer_rsrc_t(), 0u, stage, chg, TT, &ti, no_rename);
             if (wrote) {
                 reinterpret_cast<uint4 *>(tok)[(uint64_t)tile * kWave + lane] = qn;
                 if (lane == 0 && marks_all) atomicOr(&chg[tile >> 5], 1u << (tile & 31u));    // (the fused pass set no marks)
