@@ -3538,14 +3538,15 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
 
 // (one wave per pair j: column j and row j of the n x n block)
 __global__ __launch_bounds__(kWave) void k_adj_sums(const uint32_t *__restrict__ hdr_adj, BatchState *bs, const DevCtl *ctl) {
-    const uint32_t n = ctl->batch_n, j = blockIdx.x;
+    const uint32_t n = ctl->batch_n;
     if (n < 2) return;
-    uint32_t in = 0, out = 0;
-    if (j < n)
+    for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {       // (the grid is sized for the batches the host expects)
+        uint32_t in = 0, out = 0;
         for (uint32_t p = threadIdx.x; p < n; p += kWave) { in += hdr_adj[p * ctl->adj_pitch + j]; out += hdr_adj[j * ctl->adj_pitch + p]; }
-    in = wave_sum(in);
-    out = wave_sum(out);
-    if (threadIdx.x == 0) { bs->adj_in[j] = in; bs->adj_out[j] = out; }
+        in = wave_sum(in);
+        out = wave_sum(out);
+        if (threadIdx.x == 0) { bs->adj_in[j] = in; bs->adj_out[j] = out; }
+    }
 }
 
 // per pair j: the largest packed value among the pairs (x, X_j), (X_j, y) it creates
@@ -3839,7 +3840,7 @@ __device__ __forceinline__ void dense_raise_bounds(const PairTable &t, unsigned 
 }
 
 __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *ctl, const BatchState *bs,
-                                                           uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR) {
+                                                           uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR, uint32_t j_parts) {
     __shared__ uint2 tile[kApplyTile][kApplyTile + 1];
     __shared__ uint32_t keys[kApplyTile];           // bs->key[j0 ..]
     __shared__ RaiseList raise[256 / kWave];
@@ -3850,9 +3851,9 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
     const uint32_t X0 = 256u + ctl->k_done;
     // (a workgroup takes 64 ids x and walks the pairs in steps of kApplyJParts tiles of 64: the grid does not grow
     //  with the batch cap)
-    const uint32_t x0 = (blockIdx.x / kApplyJParts) * kApplyTile;
+    const uint32_t x0 = (blockIdx.x / j_parts) * kApplyTile;
     const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
-    for (uint32_t j0 = (blockIdx.x % kApplyJParts) * kApplyTile; x0 < X0 && j0 < n; j0 += kApplyJParts * kApplyTile) {
+    for (uint32_t j0 = (blockIdx.x % j_parts) * kApplyTile; x0 < X0 && j0 < n; j0 += j_parts * kApplyTile) {
         __syncthreads();                 // (the tile of the previous step is done with)
         if (threadIdx.x < (uint32_t)kApplyTile) keys[threadIdx.x] = j0 + threadIdx.x < n ? bs->key[j0 + threadIdx.x] : 0u;
         // load (and clear) the deltas of ids x0.. and pairs j0..: the rows L_j, R_j of LR are contiguous along x
@@ -4674,21 +4675,26 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
 }
 
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
-                         uint32_t *LR, uint32_t id_upper) {
+                         uint32_t *LR, uint32_t id_upper, uint32_t n_hint) {
+    // n_hint: the batch size the grids are sized for (every kernel strides over what the batch really holds)
+    if (n_hint < 64u) n_hint = 64u;
+    if (n_hint > (uint32_t)kBatchMax) n_hint = kBatchMax;
     // id_upper: upper bound of the ids that exist (the kernels read the exact value from ctl)
     const uint64_t cells = (uint64_t)id_upper * kBatchMax;
     uint32_t blocks = (uint32_t)((cells + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 8) blocks = 8;            // (k_apply_batch: at least kBatchMax threads, for the per-pair part)
-    hipLaunchKernelGGL(k_adj_sums, dim3(kBatchMax), dim3(kWave), 0, s, hdr_adj, bs, ctl);
+    hipLaunchKernelGGL(k_adj_sums, dim3(n_hint), dim3(kWave), 0, s, hdr_adj, bs, ctl);
     // (work items of k_delta_max: 4096 cells of one LR row each)
     hipLaunchKernelGGL(k_delta_max, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, LR, bs, ctl);
-    hipLaunchKernelGGL(k_adj_max, dim3(kBatchMax / 4), dim3(256), 0, s, hdr_adj, bs, ctl);
+    hipLaunchKernelGGL(k_adj_max, dim3(n_hint / 4), dim3(256), 0, s, hdr_adj, bs, ctl);
     hipLaunchKernelGGL(k_validate, dim3(1), dim3(kValThreads), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     if (t.cells) {
-        uint32_t grid = ((id_upper + kApplyTile - 1) / kApplyTile) * kApplyJParts;
-        if (grid < 1024u) grid = 1024u;             // (the rows of the ADJ block and the per-pair part: a grid stride each)
-        hipLaunchKernelGGL(k_apply_batch_dense, dim3(grid), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
+        uint32_t j_parts = (n_hint + kApplyTile - 1) / kApplyTile;       // workgroups side by side along the pairs
+        if (j_parts > kApplyJParts) j_parts = kApplyJParts;
+        uint32_t grid = ((id_upper + kApplyTile - 1) / kApplyTile) * j_parts;
+        if (grid < 256u) grid = 256u;               // (the rows of the ADJ block and the per-pair part: a grid stride each)
+        hipLaunchKernelGGL(k_apply_batch_dense, dim3(grid), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR, j_parts);
     } else {
         hipLaunchKernelGGL(k_apply_batch, dim3(blocks), dim3(256), 0, s, t, ctl, bs, hdr_m, hdr_adj, LR);
     }

@@ -322,7 +322,7 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
                         int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible = 1);
 // k_delta_max + k_validate + k_apply_batch
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
-                         uint32_t *LR, uint32_t id_upper);
+                         uint32_t *LR, uint32_t id_upper, uint32_t n_hint);
 void launch_rewrite_marked(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side, uint32_t n_tiles,
                            uint32_t *chg, uint32_t *list /* [n_tiles] scratch */, const BatchState *bs, DevCtl *ctl,
                            const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus,

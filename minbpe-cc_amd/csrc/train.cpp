@@ -949,7 +949,10 @@ static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge excha
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
     c->k_upper = std::min<uint32_t>(c->n_target, c->k_upper + std::min<uint32_t>((uint32_t)c->opt_max_batch, c->max_batch_eff));
     const uint32_t id_upper = 256 + c->k_upper;
-    launch_batch_tables(c->stream, c->tab, c->ctl, c->bs, c->hdr_m, c->hdr_adj, c->LR, id_upper);
+    // (grids of the per-batch kernels: sized for the cap while batches are large or unknown, for a few dozen pairs on
+    //  text, where a sequence merges a handful -- they stride over what the batch really holds either way)
+    const uint32_t n_hint = c->merges_per_seq > 0 && c->merges_per_seq < 128.0 ? 256u : c->max_batch_eff;
+    launch_batch_tables(c->stream, c->tab, c->ctl, c->bs, c->hdr_m, c->hdr_adj, c->LR, id_upper, n_hint);
     launch_apply(c->stream, c->tab, c->ctl, c->best, id_upper, c->LR, multi ? c->xb : nullptr, c->sums, c->side,
                  c->chg, c->n_tiles, 1);
     launch_rewrite_marked(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->tile_list, c->bs, c->ctl, le, re,
