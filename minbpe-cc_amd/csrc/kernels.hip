@@ -3788,6 +3788,9 @@ __global__ void k_apply_batch(PairTable t, DevCtl *ctl, const BatchState *bs, ui
 // A new token's pairs are plain stores; their argmax bounds are raised once per wave.
 constexpr int kApplyTile = 64;
 constexpr uint32_t kApplyJParts = 16;
+#ifndef MBPE_APPLY_LOADS
+#define MBPE_APPLY_LOADS 1
+#endif
 #ifndef MBPE_APPLY_BOUNDS
 #define MBPE_APPLY_BOUNDS 0
 #endif
@@ -3858,6 +3861,30 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
         if (threadIdx.x < (uint32_t)kApplyTile) keys[threadIdx.x] = j0 + threadIdx.x < n ? bs->key[j0 + threadIdx.x] : 0u;
         // load (and clear) the deltas of ids x0.. and pairs j0..: the rows L_j, R_j of LR are contiguous along x
         const uint32_t pitch = lr_pitch(X0);
+#if MBPE_APPLY_LOADS == 1
+        {
+            // (a wave's 32 loads are issued before its first store: the rows are independent, which the compiler cannot know)
+            constexpr uint32_t kLd = kApplyTile / (256 / kWave);
+            const uint32_t x = x0 + lane;
+            uint32_t vl[kLd], vr[kLd];
+#pragma unroll
+            for (uint32_t u = 0; u < kLd; ++u) {
+                const uint32_t j = j0 + wave + u * (256 / kWave);
+                const bool ok = x < X0 && j < n;
+                const uint32_t *cl = LR + (size_t)(2u * (ok ? j : 0u)) * pitch + (ok ? x : 0u);
+                vl[u] = ok ? *cl : 0u;
+                vr[u] = ok ? *(cl + pitch) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kLd; ++u) {
+                const uint32_t c = wave + u * (256 / kWave), j = j0 + c;
+                uint32_t *cl = LR + (size_t)(2u * j) * pitch + x;
+                if (vl[u]) *cl = 0;
+                if (vr[u]) *(cl + pitch) = 0;
+                tile[lane][c] = j < commit ? make_uint2(vl[u], vr[u]) : make_uint2(0, 0);
+            }
+        }
+#else
         for (uint32_t c = wave; c < (uint32_t)kApplyTile; c += 256 / kWave) {
             const uint32_t x = x0 + lane, j = j0 + c;
             uint2 lr = make_uint2(0, 0);
@@ -3870,6 +3897,7 @@ __global__ __launch_bounds__(256) void k_apply_batch_dense(PairTable t, DevCtl *
             }
             tile[lane][c] = lr;
         }
+#endif
         __syncthreads();
         // The decrements return the old value (an absent pair or a negative count is an error worth
         // knowing about); four of them are in flight per lane before the first one is looked at.
