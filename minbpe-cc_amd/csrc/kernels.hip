@@ -2580,10 +2580,23 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             if (cut == 0u && accepted == limit) ctl->cut_full += 1;
             // next threshold: about 128 candidates beyond this batch, or a window twice as wide
             // when the list ended before the batch was full
+#ifndef MBPE_SEL_WINDOW
+#define MBPE_SEL_WINDOW 1
+#endif
 #ifndef MBPE_SEL_AHEAD
 #define MBPE_SEL_AHEAD 2        /* halves of the batch-size limit that the next candidate list should reach beyond a batch */
 #endif
-            const uint32_t want = ci + ((uint32_t)MBPE_SEL_AHEAD * (adapt < 16u ? 16u : adapt)) / 2u;
+#if MBPE_SEL_WINDOW
+            // the window follows the batches that are being chosen (eight times their running mean, at least 256), not only
+            // the limit: on text a sequence takes a few dozen pairs and a list of thousands is sorted for nothing
+            const uint32_t recent = (3u * ctl->recent_n + accepted + 3u) / 4u;
+            ctl->recent_n = recent;
+            const uint32_t wide = 8u * recent < 256u ? 256u : 8u * recent;
+            const uint32_t adapt_w = adapt < wide ? adapt : wide;
+#else
+            const uint32_t adapt_w = adapt;
+#endif
+            const uint32_t want = ci + ((uint32_t)MBPE_SEL_AHEAD * (adapt_w < 16u ? 16u : adapt_w)) / 2u;
             if (n_l > want) {
                 ctl->sel_T = sp[want];          // (the full packed value: also cuts inside a run of equal counts)
             } else {
@@ -2599,7 +2612,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                     // every selection through the overflow path): extend by what that density needs
                     // (aiming at a list of want + adapt entries, but never at more than three quarters of what the list
                     //  holds: an overflowing gather costs two more scans and a worse threshold)
-                    unsigned long long aim = (unsigned long long)want + adapt;
+                    unsigned long long aim = (unsigned long long)want + adapt_w;
                     if (aim > 3ull * sel_cap / 4ull) aim = 3ull * sel_cap / 4ull;
                     const unsigned long long need = aim > (unsigned long long)n_l + 64ull ? aim - n_l : 64ull;
                     spread = (spread * need + n_l - 1) / n_l;

@@ -126,6 +126,7 @@ struct DevCtl {
     uint32_t n_sel_fallback;    // batches selected by the bound-walking kernel instead (statistics)
     uint32_t sel_retry;         // the first gather overflowed: a second one with a higher threshold follows
     uint32_t adapt_limit;       // batch size limit learnt from validation (0: none yet = kBatchMax)
+    uint32_t recent_n;          // running mean of the batch sizes (k_sel_pick: how far the next candidate list should reach)
     uint32_t n_sel_retry;       // statistics
     uint32_t sel_mode;          // 1: the next first gather lists block bounds (to find a threshold), not entries
     uint32_t n_ranks;           // shards of the stream (1 without multi-GPU); set at begin
