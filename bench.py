@@ -140,13 +140,14 @@ def cpu_baseline(data, merges, what):
 # floor_model.floor_ms is the streaming floor; model_ms = "all but the count deltas" scaled to the pass's tiles + the
 # count deltas of its matches, next to measured_ms.
 FLOOR_FILE = os.path.join("profiles", "r03_fused_floor.json")
-FUSED_LIMITER = ("issue and the count-delta atomics, additively: timing-only builds of the kernel on the same four passes "
-                 "(profiles/r03_fused_diag.log, tools/fused_diag.py) take 3.5 ms to copy the stream, 3.2 ms with the nine "
-                 "lookups per lane on top (hidden under the copy), 4.9 ms with everything but the two count-delta atomics per "
-                 "match and 8.0 ms as shipped: ~60 ps per match that no other work of the wave overlaps (four waves per "
-                 "SIMD, each waits for its atomics to be taken); a pass of a 2048-pair batch (1.3e8 matches) is bound by "
-                 "them.  The vector instructions (~430 per 512-slot tile, SIMDs ~60 % busy) went down with the "
-                 "prefix-form tiles of round 3 (no chains over holes), the time by 3-7 % (DESIGN.md section 4)")
+FUSED_LIMITER = ("issue and the count-delta atomics, additively: timing-only builds of the kernel on the same passes "
+                 "(floor_model.ladder_ms from profiles/r03_fused_floor.json; tools/fused_diag.py) copy the stream in ~3.5 ms, "
+                 "hide the nine lookups per lane under that, take 5-6 ms with everything but the two count-delta atomics per "
+                 "match and 8 ms (743-pair passes, 4.9e7 matches) to 14.5 ms (2048-pair passes, 1.3e8 matches) as shipped: "
+                 "56-64 ps per match that no other work of the wave overlaps (four waves per SIMD: the lookup table fills "
+                 "the LDS; six waves hide half of it, XCD-private counters nothing: DESIGN.md section 8).  The vector "
+                 "instructions (~430-460 per 512-slot tile, SIMDs ~60 % busy) went down with the prefix-form tiles of "
+                 "round 3 (no chains over holes), the time by 3-7 % (DESIGN.md section 4)")
 
 
 def published_workload(device, with_cpu):
