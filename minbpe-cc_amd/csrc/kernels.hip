@@ -2583,6 +2583,12 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
 #ifndef MBPE_SEL_WINDOW
 #define MBPE_SEL_WINDOW 1
 #endif
+#ifndef MBPE_SEL_WINDOW_MUL
+#define MBPE_SEL_WINDOW_MUL 8u
+#endif
+#ifndef MBPE_SEL_WINDOW_MIN
+#define MBPE_SEL_WINDOW_MIN 256u
+#endif
 #ifndef MBPE_SEL_AHEAD
 #define MBPE_SEL_AHEAD 2        /* halves of the batch-size limit that the next candidate list should reach beyond a batch */
 #endif
@@ -2591,7 +2597,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             // the limit: on text a sequence takes a few dozen pairs and a list of thousands is sorted for nothing
             const uint32_t recent = (3u * ctl->recent_n + accepted + 3u) / 4u;
             ctl->recent_n = recent;
-            const uint32_t wide = 8u * recent < 256u ? 256u : 8u * recent;
+            const uint32_t wide = MBPE_SEL_WINDOW_MUL * recent < MBPE_SEL_WINDOW_MIN ? MBPE_SEL_WINDOW_MIN : MBPE_SEL_WINDOW_MUL * recent;
             const uint32_t adapt_w = adapt < wide ? adapt : wide;
 #else
             const uint32_t adapt_w = adapt;
