@@ -2583,6 +2583,9 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
 #ifndef MBPE_SEL_WINDOW
 #define MBPE_SEL_WINDOW 1
 #endif
+#ifndef MBPE_SEL_TINY
+#define MBPE_SEL_TINY 64
+#endif
 #ifndef MBPE_SEL_WINDOW_MUL
 #define MBPE_SEL_WINDOW_MUL 8u
 #endif
@@ -2623,6 +2626,12 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                     const unsigned long long need = aim > (unsigned long long)n_l + 64ull ? aim - n_l : 64ull;
                     spread = (spread * need + n_l - 1) / n_l;
                     if (spread < 1) spread = 1;
+                } else if (n_l < (uint32_t)MBPE_SEL_TINY && accepted == n_l - n_skip) {
+                    // A handful of candidates and every one of them taken (or passed over): the counts have a cliff
+                    // below them -- the benchmark after the last of the 128 x 128 pairs: 65,000 then 33,000 -- and
+                    // creeping down by 1/64 of the count costs a stream pass per step.  Halve the threshold: too many
+                    // candidates come back, and the block bounds then give the right one (two more scans, no pass).
+                    spread = c_lo / 2;
                 } else if (spread < 1 + c_lo / 64) {
                     spread = 1 + c_lo / 64;
                 }
