@@ -2583,6 +2583,9 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
 #ifndef MBPE_SEL_WINDOW
 #define MBPE_SEL_WINDOW 1
 #endif
+#ifndef MBPE_SEL_NEXT_LIMIT
+#define MBPE_SEL_NEXT_LIMIT 1
+#endif
 #ifndef MBPE_SEL_TINY
 #define MBPE_SEL_TINY 64
 #endif
@@ -2601,7 +2604,12 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             const uint32_t recent = (3u * ctl->recent_n + accepted + 3u) / 4u;
             ctl->recent_n = recent;
             const uint32_t wide = MBPE_SEL_WINDOW_MUL * recent < MBPE_SEL_WINDOW_MIN ? MBPE_SEL_WINDOW_MIN : MBPE_SEL_WINDOW_MUL * recent;
-            const uint32_t adapt_w = adapt < wide ? adapt : wide;
+            // (a batch that filled its limit doubles it -- k_seq_finish -- so the next batch may be twice as large)
+            uint32_t adapt_next = adapt;
+#if MBPE_SEL_NEXT_LIMIT
+            if (cut == 0u && accepted == limit && 2u * adapt_next <= max_batch) adapt_next *= 2u;
+#endif
+            const uint32_t adapt_w = adapt_next < wide ? adapt_next : wide;
 #else
             const uint32_t adapt_w = adapt;
 #endif
