@@ -240,7 +240,7 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *   "compact_den"   compact when holes * den >= slots (default 16; 0 = never)
  *   "batch"         sequences (or single merges) per host round trip (default 16)
  *   "multi_merge"   1 = several independent merges per stream pass (default), 0 = one
- *   "max_batch"     most merges one pass may take (default 2048, limit 4096; 1024 when the stream
+ *   "max_batch"     most merges one pass may take (default and limit 4096; 1024 when the stream
  *                   is sharded over several GPUs, whose exchange grows with it)
  *   "byte_table"    1 = a batch whose pairs are all pairs of raw bytes is looked up in a byte x byte
  *                   table by the stream kernels (default), 0 = always the hashed batch table

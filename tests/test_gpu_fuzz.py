@@ -14,7 +14,7 @@ from mbpe import check
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 2048, "fused_min": 24,
+DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 4096, "fused_min": 24,
             "dense_table": -1, "threshold_select": 1, "sel_cap": 8192, "chunk_barrier": -1}
 
 

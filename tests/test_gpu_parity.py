@@ -254,7 +254,7 @@ def test_train_tiny_inputs(tr, data, vocab):
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
 
 
-DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 2048, "fused_min": 24, "hier_argmax": -1,
+DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 4096, "fused_min": 24, "hier_argmax": -1,
             "dense_table": -1, "threshold_select": 1, "sel_cap": 8192, "chunk_barrier": -1, "first_batches": 0, "byte_table": 1}
 
 
