@@ -133,7 +133,7 @@ def cpu_baseline(data, merges, what):
 # file from a timing-only build of the kernel and from the SQ counters of the shipped one; nothing is hard-coded here):
 #   copy_only_GBps   k_fused_batch with everything but the tile copy compiled out (MBPE_FUSED_DIAG=4)
 #   valu_per_tile    vector instructions the shipped kernel executes per 512-slot tile (SQ_INSTS_VALU / tiles) in the
-#                    pass that executes most (a 2048-pair batch)
+#                    pass that executes most (a 4096-pair batch)
 #   clock_GHz        shader clock during the pass (SQ_BUSY_CYCLES per shader engine / duration)
 #   ladder_ms        the same four passes with timing-only builds: copy, + lookups, all but the count deltas, shipped;
 #                    delta_ps_per_match = (shipped - all but the count deltas) / matches of a pass
@@ -143,8 +143,8 @@ FLOOR_FILE = os.path.join("profiles", "r03_fused_floor.json")
 FUSED_LIMITER = ("issue and the count-delta atomics, additively: timing-only builds of the kernel on the same passes "
                  "(floor_model.ladder_ms from profiles/r03_fused_floor.json; tools/fused_diag.py) copy the stream in ~3.5 ms, "
                  "hide the nine lookups per lane under that, take 5-6 ms with everything but the two count-delta atomics per "
-                 "match and 8 ms (743-pair passes, 4.9e7 matches) to 14.5 ms (2048-pair passes, 1.3e8 matches) as shipped: "
-                 "56-64 ps per match that no other work of the wave overlaps (four waves per SIMD: the lookup table fills "
+                 "match and 8 ms (743-pair passes, 4.9e7 matches) to 20 ms (passes of 2,100-4,096 pairs, 1.9e8 matches) as shipped: "
+                 "56-70 ps per match that no other work of the wave overlaps (four waves per SIMD: the lookup table fills "
                  "the LDS; six waves hide half of it, XCD-private counters nothing: DESIGN.md section 8).  The vector "
                  "instructions (~430-460 per 512-slot tile, SIMDs ~60 % busy) went down with the prefix-form tiles of "
                  "round 3 (no chains over holes), the time by 3-7 % (DESIGN.md section 4)")
