@@ -357,7 +357,10 @@ def main():
         # the run the stream is recounted from scratch on the device; the table must equal the recount there, and the
         # merge the trainer commits next must be the (count desc, key asc) argmax of the recounted table
         argmax_checks = None
+        whole_run_fused = None
         if dist is None and fs["n_pairs"] and vocab <= 32768:
+            tr.set_option("time_kernels", 1)      # (this second, untimed run also times every fused pass of a whole training)
+            w0 = tr.stats()
             tr.train_begin(vocab)
             argmax_checks = []
             total = vocab - 256
@@ -372,6 +375,18 @@ def main():
             tr.train_steps(total)          # to the end: the second run's merges must equal the first's
             m2, c2 = tr.train_result()
             argmax_checks.append({"second_run_identical": bool(np.array_equal(m2, merges) and np.array_equal(c2, counts))})
+            w1 = tr.stats()
+            tr.set_option("time_kernels", 0)
+            wl = w1["fused_launches"] - w0["fused_launches"]
+            if wl:
+                wms = w1["ms_fused_kernel"] - w0["ms_fused_kernel"]
+                wb = 4.0 * (w1["fused_slots"] - w0["fused_slots"])
+                whole_run_fused = {"launches": wl, "avg_launch_ms": wms / wl, "achieved": wb / (wms * 1e-3) / 1e9,
+                                   "unit": "GB/s", "frac": wb / (wms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "is": "every fused pass of a whole training (the checkpoint run), bytes = 2 B read + 2 B "
+                                         "written per slot of each pass: the timed window above holds the batches of "
+                                         "thousands of pairs, which their count-delta atomics bound; most passes of a run "
+                                         "are small batches on a shorter stream"}
         full_run = {"merges": int(len(merges)), "seconds": f_el, "merges_per_s": len(merges) / f_el,
                     "passes": fs["n_batches"], "fused_passes": fs["n_fused"], "fused_abandoned": fs["n_fused_dropped"],
                     "begin_ms": fs["ms_begin"], "steps_ms": fs["ms_steps"], "compactions": fs["n_compactions"],
@@ -494,6 +509,7 @@ def main():
                 "stream_passes": n_pass,
                 "merges_per_pass": done / max(n_pass, 1),
                 "floor_model": floor_model,
+                "whole_run": whole_run_fused if not args.no_full_run else None,
                 "survey_8d_model": {
                     "note": "SURVEY 8(d) counts 2 B x L read + 2 B x L' written PER MERGE; one pass serves "
                             "merges_per_pass merges, so that sum over the pass's merges divided by the pass time "
