@@ -2583,6 +2583,9 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
 #ifndef MBPE_SEL_WINDOW
 #define MBPE_SEL_WINDOW 1
 #endif
+#ifndef MBPE_SEL_AIM_NEXT
+#define MBPE_SEL_AIM_NEXT 0      /* eighths of the list that the entries BEHIND a batch may fill (0: three quarters, batch included) */
+#endif
 #ifndef MBPE_SEL_NEXT_LIMIT
 #define MBPE_SEL_NEXT_LIMIT 1
 #endif
@@ -2629,8 +2632,15 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
                     // every selection through the overflow path): extend by what that density needs
                     // (aiming at a list of want + adapt entries, but never at more than three quarters of what the list
                     //  holds: an overflowing gather costs two more scans and a worse threshold)
+#if MBPE_SEL_AIM_NEXT
+                    // (what this batch took is gone from the next list: the bound is on what comes BEHIND it)
+                    unsigned long long aim_next = (unsigned long long)(want - ci) + adapt_w;
+                    if (aim_next > (unsigned long long)MBPE_SEL_AIM_NEXT * sel_cap / 8ull) aim_next = (unsigned long long)MBPE_SEL_AIM_NEXT * sel_cap / 8ull;
+                    const unsigned long long aim = (unsigned long long)ci + aim_next;
+#else
                     unsigned long long aim = (unsigned long long)want + adapt_w;
                     if (aim > 3ull * sel_cap / 4ull) aim = 3ull * sel_cap / 4ull;
+#endif
                     const unsigned long long need = aim > (unsigned long long)n_l + 64ull ? aim - n_l : 64ull;
                     spread = (spread * need + n_l - 1) / n_l;
                     if (spread < 1) spread = 1;
