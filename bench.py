@@ -4,24 +4,29 @@
 Contract (driver): python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by torch.distributed.run, one rank per GPU.
 
-A "step" is one *batch sequence*, the unit the library executes (mbpe_train_sequences):
-select the next maxima that are provably independent -> ONE pass over the token stream that
-merges them all -> validate against the reference's one-at-a-time order -> apply the count
-updates.  It is the loop body of the reference (Tokenizer.h:557-589: get_top_pair_count,
-merge_chunks -> merge_incremental) for up to 1024 consecutive iterations at once.  W warm-up
-sequences run untimed, then exactly K sequences are timed between barriers;
-    value = merges those K sequences committed / wall time       (merges/s, whole job)
+A "step" is ONE WHOLE TRAINING of the workload: mbpe_train_begin (pair-count scan, slot stream, pair
+table, first argmax) + the loop Tokenizer.h:557-589 run to the target vocabulary (31,744 merges on the
+default workload) -- one pass of the hot path over one batch of synthetic input.  W trainings run
+untimed, then exactly K trainings are timed between barriers;
+    value = K x merges of one training / wall time                 (merges/s, whole job)
+so the headline is the end-to-end number of a training run, not a window of it.
 
 Workload (--config synthetic, the default): BASELINE.json config 4 -- SplitMix64(seed 42)
 uniform-random bytes, 4 GiB whole job, `basic` encoder (one chunk), vocab 32,000.  The corpus is
 generated on the device, so it is resident in HBM before anything is timed; the pair-count scan
-(the other half of BASELINE.json's metric) is timed on its own (pair_count_scan_*).
+(the other half of BASELINE.json's metric) is part of every step and is also timed on its own
+(roofline_pair_count: start/stop events of each dispatch).
 --config bible: BASELINE.json config 3 with the documented stand-in corpus (data/bible.txt is absent
 from the reference checkout): shakespeare.txt x 4 = 4,461,576 bytes, vocab 10,000.
 
-After the timed region, outside it, the same process runs the WHOLE training to the target
-vocabulary (`full_run`) and checks the result on the device (`checks`): decode(stream) == corpus,
-chosen counts never increase, every rank holds the same merges.
+`roofline` describes the kernel that dominates the timed steps (k_fused_batch) over EVERY launch of it
+inside the timed region (HIP events on the library's stream): `achieved` prices SURVEY.md 8(d)'s
+algorithmic bytes -- 2 B per live token read + 2 B per live token written -- and `achieved_slot_bytes`
+what the kernel physically moves (2 B + 2 B per slot, holes included).
+
+After the timed region, outside it, the result of the last training is checked on the device
+(`checks`): decode(stream) == corpus, chosen counts never increase, every rank holds the same merges,
+and a further training is stopped at checkpoints where the table is compared with a recount.
 
 Rank 0 prints ONE JSON line.
 """
@@ -37,7 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, "minbpe-cc_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 GOLDEN = 0x9E3779B97F4A7C15
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
 
 
 def _s64(v):
@@ -204,8 +209,8 @@ def fused_floor():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="batch sequences timed")
-    ap.add_argument("--warmup", type=int, default=5, help="batch sequences before the timed region")
+    ap.add_argument("--steps", type=int, default=3, help="whole trainings timed")
+    ap.add_argument("--warmup", type=int, default=1, help="whole trainings before the timed region")
     ap.add_argument("--config", choices=["synthetic", "bible"], default="synthetic")
     ap.add_argument("--bytes", type=int, default=4 << 30, help="corpus bytes, whole job (synthetic)")
     ap.add_argument("--vocab", type=int, default=0, help="default 32000 (synthetic) / 10000 (bible)")
@@ -213,7 +218,7 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--cpu-merges", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-full-run", action="store_true", help="skip the untimed full training + checks")
+    ap.add_argument("--no-full-run", action="store_true", help="skip the untimed checks after the timed region")
     args = ap.parse_args()
 
     import numpy as np
@@ -270,35 +275,49 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ---- timed region: K sequences after W warm-up sequences
-    tr.set_option("time_kernels", 1)
-    tr.train_begin(vocab)
-    begin_stats = tr.stats()
-    warm_merges = tr.train_sequences(args.warmup) if args.warmup else 0
+    def one_training():
+        """One step: the whole training.  Returns (merges, seconds, stats after it)."""
+        t = time.perf_counter()
+        tr.train_begin(vocab)
+        n = tr.train_steps(vocab - 256)          # (ends with a host synchronisation on the library's stream)
+        return n, time.perf_counter() - t, tr.stats()
+
+    # ---- timed region: K whole trainings after W warm-up trainings
+    tr.set_option("time_kernels", 1)            # HIP events around the stream kernels of every sequence (4 records each)
+    for _ in range(args.warmup):
+        one_training()
     s0 = tr.stats()
     barrier()
     t0 = time.perf_counter()
-    done = tr.train_sequences(args.steps)
+    steps = [one_training() for _ in range(args.steps)]
     barrier()
     t1 = time.perf_counter()
     s1 = tr.stats()
     elapsed = max_over_ranks(t1 - t0)
+    done = sum(n for n, _, _ in steps)
+    per_training = steps[-1][0] if steps else 0
+    last = steps[-1][2] if steps else s1
 
     # ---- the dominant kernel inside the timed region.  A fused pass (k_fused_batch) reads the stream once,
-    # counts the deltas of every pair of the batch and writes the merged stream to the other buffer:
-    # 2 B read + 2 B written per slot.  Small batches take the read-only pass (k_scan_batch / k_merge).
-    n_pass = s1["n_batches"] - s0["n_batches"]
+    # counts the deltas of every pair of the batch and writes the merged stream to the other buffer.
+    # Algorithmic bytes (SURVEY 8d): 2 B x L read + 2 B x L' written, L / L' the live tokens before / after the pass;
+    # physically it moves 2 B + 2 B per SLOT (holes are squeezed out only at a compaction).
+    n_pass = sum(st["n_batches"] for _, _, st in steps)
     n_fused = s1["fused_launches"] - s0["fused_launches"]
     n_other = (s1["merge_launches"] - s0["merge_launches"]) - n_fused
     ms_fused = s1["ms_fused_kernel"] - s0["ms_fused_kernel"]
     ms_all = s1["ms_merge_kernel"] - s0["ms_merge_kernel"]
+    slot_bytes = None
     if n_fused > 0 and ms_fused >= 0.5 * ms_all:
         roof_name = "k_fused_batch"
-        roof_desc = ("reads the stream once, counts the deltas of every pair of the batch and writes the "
-                     "merged stream to the other buffer (2 B read + 2 B written per slot)")
+        roof_desc = ("reads the stream once, counts the deltas of every pair of the batch and writes the merged stream "
+                     "to the other buffer; `achieved` = SURVEY 8(d)'s bytes (2 B per live token read + 2 B per live token "
+                     "written) over the kernel's time, `achieved_slot_bytes` = what it moves (2 B + 2 B per slot, holes "
+                     "included), both over every launch of the timed trainings")
         launches = n_fused
         avg_ms = ms_fused / n_fused
-        pass_bytes = 4.0 * (s1["fused_slots"] - s0["fused_slots"]) / n_fused
+        pass_bytes = 2.0 * (s1["fused_live_tokens"] - s0["fused_live_tokens"]) / n_fused
+        slot_bytes = 4.0 * (s1["fused_slots"] - s0["fused_slots"]) / n_fused
         limiter = FUSED_LIMITER
     else:
         roof_name = "k_scan_batch"
@@ -308,93 +327,52 @@ def main():
         pass_bytes = 2.0 * s1["n_slots"]
         limiter = None
     achieved = pass_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # what a fused pass cannot go below: its bytes at the rate of the copy-only build of the same kernel, and its vector
-    # instructions at one per 4 cycles and SIMD (wave64 on a SIMD that retires 16 lanes per cycle); the larger one binds
+    achieved_slots = slot_bytes / (avg_ms * 1e-3) / 1e9 if slot_bytes and avg_ms > 0 else None
+    # what a fused pass cannot go below: its bytes at the rate of the copy-only build of the same kernel; and the ladder
+    # of timing-only builds that explains the rest (profiles/, written by committed scripts)
     floor_model = None
     if roof_name == "k_fused_batch":
         fl = fused_floor()
         if fl:
-            tiles = (s1["fused_slots"] - s0["fused_slots"]) / n_fused / 512.0
-            stream_ms = pass_bytes / (fl["copy_only_GBps"] * 1e9) * 1e3
-            valu_ms = fl["valu_per_tile"] * tiles * 4.0 / (fl["simds"] * fl["clock_GHz"] * 1e9) * 1e3
-            matches = (s0["n_live"] - s1["n_live"]) / max(n_pass, 1)
+            tiles = slot_bytes / 4.0 / 512.0
+            stream_ms = slot_bytes / (fl["copy_only_GBps"] * 1e9) * 1e3
+            matches = (len(steps) * (hi - lo) - sum(st["n_live"] for _, _, st in steps)) / max(n_pass, 1)
             lad = fl.get("ladder_ms") or {}
             full_tiles = 4294967296.0 / 512.0           # the ladder was measured on passes over 2^32 slots
             no_delta_ms = lad.get("all_but_count_deltas") * tiles / full_tiles if lad.get("all_but_count_deltas") else None
             delta_ms = fl["delta_ps_per_match"] * matches * 1e-9 if fl.get("delta_ps_per_match") else None
             floor_model = {"stream_ms": stream_ms, "copy_only_GBps": fl["copy_only_GBps"],
-                           "valu_issue_ms": valu_ms, "valu_per_tile_heaviest_pass": fl["valu_per_tile"],
-                           "tiles_per_launch": tiles, "clock_GHz": fl["clock_GHz"], "simds": fl["simds"],
-                           "matches_per_launch": matches,
+                           "tiles_per_launch": tiles, "matches_per_launch": matches,
                            "ladder_ms": lad, "ladder_matches_per_launch": fl.get("ladder_matches_per_launch"),
                            "all_but_count_deltas_ms": no_delta_ms, "count_deltas_ms": delta_ms,
                            "model_ms": (no_delta_ms + delta_ms) if no_delta_ms and delta_ms else None,
                            "floor_ms": stream_ms, "measured_ms": avg_ms,
                            "sources": FLOOR_FILE + " (" + fl.get("sources", "") + ")"}
-    # SURVEY.md 8(d) prices a merge step at 2 B x L read + 2 B x L' written; a pass performs
-    # merges_per_pass of them on one read: the same sum divided by the measured time
-    live_avg = 0.5 * (s0["n_live"] + s1["n_live"])
-    ref_model_bytes = 4.0 * live_avg * (done / max(n_pass, 1))
-    timed = {"sequences": args.steps, "stream_passes": n_pass, "merges": done,
-             "first_merge": warm_merges, "fused_passes": n_fused,
-             "slots_begin": s0["n_slots"], "live_begin": s0["n_live"], "live_end": s1["n_live"],
-             "seconds": elapsed, "ms_stream_kernels": ms_all, "ms_fused_kernel": ms_fused}
+    timed = {"trainings": args.steps, "merges": done, "merges_per_training": per_training,
+             "stream_passes": n_pass, "fused_passes": n_fused,
+             "seconds": elapsed, "seconds_each": [round(sec, 5) for _, sec, _ in steps],
+             "ms_stream_kernels": ms_all, "ms_fused_kernel": ms_fused,
+             "live_end": last["n_live"], "slots_end": last["n_slots"],
+             "includes": "pair-count scan, stream + table setup, every sequence, host housekeeping (compactions)"}
 
-    # ---- untimed: the whole training to the target vocabulary, then checks on the device
+    # ---- untimed: checks of the last timed training's result on the device, then a further training stopped at checkpoints
     full_run, checks = None, None
-    if not args.no_full_run:
+    if steps:
+        sec = [x for _, x, _ in steps]
+        full_run = {"merges": per_training, "seconds": sum(sec) / len(sec), "seconds_best": min(sec),
+                    "merges_per_s": done / elapsed if elapsed > 0 else 0.0,
+                    "is": "one training of the timed region (the value above is exactly this: a step is a whole training)",
+                    "passes": last["n_batches"], "fused_passes": last["n_fused"], "fused_abandoned": last["n_fused_dropped"],
+                    "begin_ms": last["ms_begin"], "steps_ms": last["ms_steps"],
+                    "compactions": (s1["n_compactions"] - s0["n_compactions"]) / max(len(steps), 1),
+                    "live_end": last["n_live"], "slots_end": last["n_slots"], "pairs": last["n_pairs"],
+                    "selection": {k: last[k] for k in ("n_sel_retry", "n_sel_fallback", "cut_conflict", "cut_bucket",
+                                                       "cut_single", "cut_full", "n_skipped", "n_skip_cut",
+                                                       "n_validation_drops")}}
+    if not args.no_full_run and steps:
         tr.set_option("time_kernels", 0)
-        barrier()
-        f0 = time.perf_counter()
-        tr.train_begin(vocab)
-        n_done = tr.train_steps(vocab - 256)
-        barrier()
-        f1 = time.perf_counter()
-        fs = tr.stats()
-        f_el = max_over_ranks(f1 - f0)
         merges, counts = tr.train_result()
-        # ---- the ORDER of merges at full size (untimed, a second training on one GPU): at checkpoints spread over
-        # the run the stream is recounted from scratch on the device; the table must equal the recount there, and the
-        # merge the trainer commits next must be the (count desc, key asc) argmax of the recounted table
-        argmax_checks = None
-        whole_run_fused = None
-        if dist is None and fs["n_pairs"] and vocab <= 32768:
-            tr.set_option("time_kernels", 1)      # (this second, untimed run also times every fused pass of a whole training)
-            w0 = tr.stats()
-            tr.train_begin(vocab)
-            argmax_checks = []
-            total = vocab - 256
-            for frac in (0.0, 0.12, 0.35, 0.6, 0.8, 0.9, 0.97):
-                target = int(total * frac)
-                have = len(tr.train_result()[0])
-                if target > have:
-                    tr.train_steps(target - have)
-                if len(tr.train_result()[0]) >= total:
-                    break
-                argmax_checks.append(C.argmax_at_checkpoint(tr, torch, device))
-            tr.train_steps(total)          # to the end: the second run's merges must equal the first's
-            m2, c2 = tr.train_result()
-            argmax_checks.append({"second_run_identical": bool(np.array_equal(m2, merges) and np.array_equal(c2, counts))})
-            w1 = tr.stats()
-            tr.set_option("time_kernels", 0)
-            wl = w1["fused_launches"] - w0["fused_launches"]
-            if wl:
-                wms = w1["ms_fused_kernel"] - w0["ms_fused_kernel"]
-                wb = 4.0 * (w1["fused_slots"] - w0["fused_slots"])
-                whole_run_fused = {"launches": wl, "avg_launch_ms": wms / wl, "achieved": wb / (wms * 1e-3) / 1e9,
-                                   "unit": "GB/s", "frac": wb / (wms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "is": "every fused pass of a whole training (the checkpoint run), bytes = 2 B read + 2 B "
-                                         "written per slot of each pass: the timed window above holds the batches of "
-                                         "thousands of pairs, which their count-delta atomics bound; most passes of a run "
-                                         "are small batches on a shorter stream"}
-        full_run = {"merges": int(len(merges)), "seconds": f_el, "merges_per_s": len(merges) / f_el,
-                    "passes": fs["n_batches"], "fused_passes": fs["n_fused"], "fused_abandoned": fs["n_fused_dropped"],
-                    "begin_ms": fs["ms_begin"], "steps_ms": fs["ms_steps"], "compactions": fs["n_compactions"],
-                    "live_end": fs["n_live"], "slots_end": fs["n_slots"], "pairs": fs["n_pairs"],
-                    "selection": {k: fs[k] for k in ("n_sel_retry", "n_sel_fallback", "cut_conflict", "cut_bucket",
-                                                     "cut_single", "cut_full", "n_skipped", "n_skip_cut",
-                                                     "n_validation_drops")},
-                    "includes": "pair-count scan, stream + table setup, every sequence, host housekeeping"}
+        # decode(final stream) == corpus
         if dist is None:
             ref = corpus
         else:
@@ -415,6 +393,25 @@ def main():
         if dist is not None:
             rt["decoded_total_all_ranks"] = int(sum(lens))
             rt["ok"] = bool(rt["ok"] and sum(lens) == total_bytes)
+        # ---- the ORDER of merges at full size (a further training on one GPU): at checkpoints spread over the run the
+        # stream is recounted from scratch on the device; the table must equal the recount there, and the merge the
+        # trainer commits next must be the (count desc, key asc) argmax of the recounted table
+        argmax_checks = None
+        if dist is None and last["n_pairs"] and vocab <= 32768:
+            tr.train_begin(vocab)
+            argmax_checks = []
+            total = vocab - 256
+            for frac in (0.0, 0.12, 0.35, 0.6, 0.8, 0.9, 0.97):
+                target = int(total * frac)
+                have = len(tr.train_result()[0])
+                if target > have:
+                    tr.train_steps(target - have)
+                if len(tr.train_result()[0]) >= total:
+                    break
+                argmax_checks.append(C.argmax_at_checkpoint(tr, torch, device))
+            tr.train_steps(total)          # to the end: this run's merges must equal the timed run's
+            m2, c2 = tr.train_result()
+            argmax_checks.append({"second_run_identical": bool(np.array_equal(m2, merges) and np.array_equal(c2, counts))})
         digest = hashlib.sha256(merges.tobytes() + counts.tobytes()).hexdigest()
         same = True
         if dist is not None:
@@ -442,20 +439,23 @@ def main():
 
     # ---- pair-count scan (the north star's graded kernel), timed last: an idle chip needs ~25 launches of this
     # kernel (some tens of milliseconds of work) to reach its sustained clock -- launch times fall by a fifth
-    # meanwhile -- and by now the process has kept it busy for a while.  5 launches of warm-up, then the MEAN of
-    # 30 launches (three groups of ten, back to back inside one pair of HIP events each: a marker per launch adds
-    # 20-45 us to a 1 ms kernel, which rocprofv3's per-dispatch durations do not contain).
-    scan_ms = []
+    # meanwhile -- and by now the process has kept it busy for a while.  5 launches of warm-up, then 30 launches in
+    # three groups of ten back to back; every dispatch carries its own start / stop events (hipExtLaunchKernelGGL),
+    # so avg_launch_ms is the mean KERNEL duration -- no gap between launches, no marker -- which is what rocprofv3
+    # reports per dispatch.  (ms_bracket: the same launches between one pair of stream events per group, gaps included.)
+    scan_ms, scan_bracket = [], []
     for _ in range(5):
         tr.pair_count_u8(want_table=False)
-        scan_ms.append(tr.stats()["ms_pair_count"])
-    tr.set_option("pc_repeat", 10)           # 3 x 10 launches back to back: one pair of HIP events around each ten
+        scan_ms.append(tr.stats()["ms_pair_count_kernel"])
+    tr.set_option("pc_repeat", 10)
     for _ in range(3):
         tr.pair_count_u8(want_table=False)
-        scan_ms.append(tr.stats()["ms_pair_count"])
+        st = tr.stats()
+        scan_ms.append(st["ms_pair_count_kernel"])
+        scan_bracket.append(st["ms_pair_count"])
     tr.set_option("pc_repeat", 1)
     scan_ms_avg = sum(scan_ms[5:]) / 3.0
-    scan_gbs = (hi - lo) / (scan_ms_avg * 1e-3) / 1e9
+    scan_gbs = (hi - lo) / (scan_ms_avg * 1e-3) / 1e9 if scan_ms_avg > 0 else 0.0
 
     if rank == 0:
         if bible:
@@ -467,7 +467,7 @@ def main():
                         "encoder (one chunk), vocab %d, lexicographic tie-break" % (args.seed, total_bytes, vocab))
         out = {
             "metric": "bpe_train_merges_per_sec",
-            "value": done / elapsed,
+            "value": done / elapsed if elapsed > 0 else 0.0,
             "unit": "merges/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -479,16 +479,15 @@ def main():
             "dtype": "u16",
             "data": "synthetic" if not bible else "shakespeare.txt x 4 (fixture)",
             "config": {
-                "workload": workload + "; a step is one batch sequence (select -> one stream pass -> validate -> "
-                            "apply), timed steps are sequences %d..%d = merges %d..%d"
-                            % (args.warmup, args.warmup + args.steps, warm_merges, warm_merges + done),
+                "workload": workload + "; a step is ONE WHOLE TRAINING (pair-count scan, stream and table setup, every "
+                            "merge up to the vocabulary: %d merges)" % per_training,
                 "corpus_bytes": total_bytes,
                 "vocab_size": vocab,
                 "parallelism": "stream sharded over %d GPU(s), pair table replicated, one sum all-reduce of the "
                                "count deltas per sequence" % world,
             },
             "timed_region": timed,
-            "merges_per_step": done / max(args.steps, 1),
+            "merges_per_step": per_training,
             "pair_count_scan_MBps": scan_gbs * 1e3 * world,
             "pair_count_scan_ms": scan_ms_avg,
             "roofline": {
@@ -499,24 +498,19 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "achieved_slot_bytes": achieved_slots,
+                "frac_slot_bytes": achieved_slots / HBM_PEAK_GBS if achieved_slots else None,
                 "traffic": pmc_traffic(roof_name, args.config, total_bytes, vocab, world),
                 "traffic_source": PMC_FILE + " (rocprofv3 PMC passes of this workload; null when none was taken "
                                   "for this kernel / configuration)",
                 "limiter": limiter,
                 "algorithmic_bytes_per_launch": pass_bytes,
+                "slot_bytes_per_launch": slot_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches": launches,
                 "stream_passes": n_pass,
                 "merges_per_pass": done / max(n_pass, 1),
                 "floor_model": floor_model,
-                "whole_run": whole_run_fused if not args.no_full_run else None,
-                "survey_8d_model": {
-                    "note": "SURVEY 8(d) counts 2 B x L read + 2 B x L' written PER MERGE; one pass serves "
-                            "merges_per_pass merges, so that sum over the pass's merges divided by the pass time "
-                            "exceeds the HBM peak: the saving is algorithmic, the kernel itself runs at `achieved`",
-                    "bytes_per_pass": ref_model_bytes,
-                    "effective_GBps": ref_model_bytes / (elapsed / max(n_pass, 1)) / 1e9,
-                },
             },
             "roofline_pair_count": {
                 "kernel": "k_pair_count_u8",
@@ -528,18 +522,22 @@ def main():
                 "traffic": pmc_traffic("k_pair_count_u8", args.config, total_bytes, vocab, world),
                 "algorithmic_bytes_per_launch": hi - lo,
                 "avg_launch_ms": scan_ms_avg,
-                "avg_launch_ms_is": "mean of launches 6-35 of 35 (three groups of ten launches back to back, HIP events "
-                                    "around each group), after 5 warm-up launches, taken after the training runs of this "
-                                    "process (chip at its sustained clock)",
+                "avg_launch_ms_is": "mean kernel duration of launches 6-35 of 35 (three groups of ten launches back to back), "
+                                    "each dispatch timed by its own start/stop events (hipExtLaunchKernelGGL), after 5 "
+                                    "warm-up launches, taken after the training runs of this process (chip at its "
+                                    "sustained clock)",
                 "launch_ms_all": [round(x, 4) for x in scan_ms],
-                "launch_ms_all_is": "5 single launches (warm-up), then the mean launch time of each group of ten",
+                "launch_ms_all_is": "5 single launches (warm-up), then the mean kernel duration of each group of ten",
+                "ms_bracket": [round(x, 4) for x in scan_bracket],
+                "ms_bracket_is": "the same groups of ten between ONE pair of stream events, per launch: gaps between "
+                                 "launches included",
             },
-            "begin_ms": begin_stats["ms_begin"],
+            "begin_ms": last["ms_begin"],
             "full_run": full_run,
             "checks": checks,
-            "batches": {k: s1[k] for k in ("n_batches", "n_fused", "n_fused_dropped", "cut_conflict", "cut_bucket",
-                                           "cut_single", "cut_full", "n_validation_drops", "n_sel_fallback",
-                                           "n_sel_retry", "size_hist", "n_skipped", "n_skip_cut")},
+            "batches": {k: last[k] for k in ("n_batches", "n_fused", "n_fused_dropped", "cut_conflict", "cut_bucket",
+                                             "cut_single", "cut_full", "n_validation_drops", "n_sel_fallback",
+                                             "n_sel_retry", "size_hist", "n_skipped", "n_skip_cut")},
         }
         if not args.no_cpu_baseline and world == 1:
             if bible:

@@ -16,13 +16,14 @@
  *     reference's Tokenizer, which is not thread-safe: Tokenizer.h:67-72)
  *   - there is NO CPU fallback: without a usable HIP device mbpe_create fails
  *
- * Token ids: the device stream holds 16-bit slots.  vocab_size may be at most
- * MBPE_MAX_VOCAB_BASIC for a single-chunk corpus and MBPE_MAX_VOCAB_CHUNKED
- * when chunk boundaries are present.  Up to MBPE_MAX_VOCAB_ENDBIT a chunked
- * stream marks "last token of its chunk" with one slot bit; beyond that it
- * keeps a barrier slot after every chunk instead (one more slot per chunk,
- * ids use all 16 bits).  Larger requests return MBPE_ERR_VOCAB; the
- * reference's Token is a uint32_t (Tokenizer.h:37).
+ * Token ids: the reference's Token is a uint32_t (Tokenizer.h:37-38).  The device stream holds
+ * 16-bit slots while the ids allow it: up to MBPE_MAX_VOCAB_BASIC for a single-chunk corpus and
+ * MBPE_MAX_VOCAB_CHUNKED when chunk boundaries are present (up to MBPE_MAX_VOCAB_ENDBIT a chunked
+ * stream marks "last token of its chunk" with one slot bit; beyond that it keeps a barrier slot
+ * after every chunk instead: one more slot per chunk, ids use all 16 bits).  A larger vocab_size
+ * (up to MBPE_MAX_VOCAB_WIDE) trains its first merges on the slot stream and the rest on 32-bit
+ * tokens with 64-bit pair keys (csrc/wide.h: one merge per pass; lexical tie-break, one GPU --
+ * with the `first` tie-break or several ranks such a request still returns MBPE_ERR_VOCAB).
  */
 #ifndef MBPE_H
 #define MBPE_H
@@ -38,6 +39,7 @@ extern "C" {
 #define MBPE_MAX_VOCAB_BASIC   65534u
 #define MBPE_MAX_VOCAB_ENDBIT  32766u
 #define MBPE_MAX_VOCAB_CHUNKED 65518u
+#define MBPE_MAX_VOCAB_WIDE    16777216u   /* 2^24: the 32-bit continuation */
 #define MBPE_NO_BARRIER 0xFFFFFFFFu
 
 typedef enum {
@@ -47,7 +49,8 @@ typedef enum {
     MBPE_ERR_ARG       = -1,  /* bad argument (NULL, vocab_size < 256: Tokenizer.h:492) */
     MBPE_ERR_NO_DEVICE = -2,  /* no HIP device / extension unusable */
     MBPE_ERR_HIP       = -3,  /* a HIP runtime call failed */
-    MBPE_ERR_VOCAB     = -4,  /* vocab_size beyond the 16-bit slot format */
+    MBPE_ERR_VOCAB     = -4,  /* vocab_size beyond MBPE_MAX_VOCAB_WIDE, or beyond the 16-bit slot format where the
+                                 32-bit continuation does not apply (`first` tie-break, several ranks) */
     MBPE_ERR_STATE     = -5,  /* call order violated (e.g. steps before begin) */
     MBPE_ERR_OOM       = -6,  /* device or host allocation failed */
     MBPE_ERR_REGEX     = -7,  /* PCRE2 unavailable, compile or match error */
@@ -99,6 +102,11 @@ typedef struct {
     uint64_t exchange_words;   /* multi-GPU: u32 words sum-all-reduced for the count deltas of all sequences so far */
     uint32_t exchanges;        /* ... in this many all-reduces (one per sequence) */
     uint32_t pad_;
+    uint64_t fused_live_tokens; /* "time_kernels": live tokens before + live tokens after, summed over the timed fused
+                                   passes (x 2 bytes = SURVEY 8(d)'s 2 B x L read + 2 B x L' written of those passes) */
+    float    ms_pair_count_kernel; /* mbpe_pair_count_u8 without a table: mean KERNEL duration of the call's launches
+                                   (start/stop events of each dispatch: no gap between launches, no marker overhead) */
+    uint32_t pad2_;
 } mbpe_stats;
 
 MBPE_API const char *mbpe_last_error(void);

@@ -21,6 +21,7 @@
 // needs a workgroup barrier.  Waves walk the tiles with a grid stride and
 // prefetch their next tile while working on the current one.
 #include "mbpe_dev.h"
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 
@@ -33,6 +34,31 @@ constexpr uint32_t kSent = 0x10000u;   // "nothing in this lane" (not a 16-bit v
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// whole-wave shifts by one lane (DPP): lane i takes lane i+1 / lane i-1, the last / first lane takes `edge`
+__device__ __forceinline__ uint32_t wave_from_next(uint32_t v, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false);     // wave_shl:1
+}
+__device__ __forceinline__ uint32_t wave_from_prev(uint32_t v, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false);     // wave_shr:1
+}
+// this lane's bit of a wave mask, as a condition (one v_cndmask at the use, no 64-bit lane arithmetic)
+__device__ __forceinline__ bool lane_of(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
+#define MBPE_GLOBAL_AS __attribute__((address_space(1)))
+// the stream's tile loads and the fused pass's tile stores as non-temporal accesses (A/B: does the Infinity Cache then
+// keep the count-delta block, which the atomics of a large batch hit at random?)
+#ifndef MBPE_NT_STREAM
+#define MBPE_NT_STREAM 0
+#endif
+// a wave-uniform address, pinned to scalar registers
+__device__ __forceinline__ uintptr_t uniform_ptr(uintptr_t p) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return ((uintptr_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint32_t rlane(uint32_t v, uint32_t uniform_lane) {
     return __builtin_amdgcn_readlane(v, rfl(uniform_lane));
 }
@@ -92,9 +118,13 @@ __device__ __forceinline__ uint32_t wave_sum_le8(uint32_t v, unsigned long long 
 // 2j + 1 (R_j) of `pitch` cells each, pitch = lr_pitch(ids that exist when the sequence starts), so that the cells a
 // batch of n pairs can touch are the prefix [0, 2 * n * pitch) of the block -- what a multi-GPU run exchanges:
 //   L_j[x] = LR[lr_idx(pitch, x, j, 0)],  R_j[y] = LR[lr_idx(pitch, y, j, 1)]
-// (largest index: 2048 rows of 65,536 cells = 2^27)
+// (largest index: 2 * kBatchMax rows of at most 65,536 cells = 2^29 at the cap of 4096.  The fused pass feeds idx << 2
+//  to a buffer atomic as a 32-bit byte offset -- num_records 0xFFFFFFFC -- so the whole block has to stay below 4 GiB)
+static_assert(2ull * kBatchMax * 65536ull * 4ull <= 0x100000000ull,
+              "the LR block must be addressable with a 32-bit byte offset (lr_idx, lr_rsrc)");
+static_assert(2u * kBatchMax < (1u << 24), "lr_idx multiplies the row with v_mad_u32_u24");
 __device__ __forceinline__ uint32_t lr_idx(uint32_t pitch, uint32_t x, uint32_t j, uint32_t side) {
-    return __umul24(2u * j + side, pitch) + x;          // (row < 2048, pitch <= 65,536: one v_mad_u32_u24)
+    return __umul24(2u * j + side, pitch) + x;          // (row < 2 * kBatchMax, pitch <= 65,536: one v_mad_u32_u24)
 }
 
 // Count deltas of frequent neighbours.  In text a pair such as ("e", " ") has millions of
@@ -313,6 +343,10 @@ constexpr int kPcVpl = 2;                  // fast loop: vectors per lane and it
 #endif
 constexpr uint32_t kPcSeg0 = MBPE_PC_SEG0;  // first segment, in fast iterations of 32 Ki pairs
 constexpr uint32_t kPcSegMax = 4096;
+// one-chunk corpora take k_pair_count_u8_fast (0: k_pair_count_u8 for every corpus, A/B)
+#ifndef MBPE_PC_FAST
+#define MBPE_PC_FAST 1
+#endif
 
 __device__ __forceinline__ uint32_t pc_table_index(uint32_t hbin) {
 #ifndef MBPE_PC_NOHASH
@@ -587,6 +621,168 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__r
             if (MASKED && ((endmask[i >> 3] >> (i & 7)) & 1u)) continue;
             atomicAdd(&bp[((uint32_t)text[i] << 8) | text[i + 1]], 1u);
         }
+    }
+}
+
+// ---- pair-count scan, one-chunk corpora: the same histogram, a leaner loop around it (round 4) ----------------------
+// The LDS alone needs 0.81 ms for 2^32 random ds_add_u32 from 1024-thread workgroups (tools/lds_atomic_floor.hip: 7.1
+// LDS cycles per wave instruction against 4.2 without bank conflicts), and the 4.75 vector instructions per pair of
+// pc_lean_pairs on register data 0.89 ms.  k_pair_count_u8 ran at 1.05 ms because of what surrounds them: per vector a
+// 64-bit clamped address, a byte load for lane 63's straddling pair, a ds_bpermute for the other lanes' (an LDS
+// instruction itself) and the bookkeeping of which pairs count -- 6.7 vector instructions per pair all told.  Here
+//   * every WAVE owns a contiguous stripe of its workgroup's range and walks it in 2-KiB blocks, lane l holding bytes
+//     [32 l, 32 l + 32) of the block (two 16-byte loads): 31 of its 32 pairs lie inside the lane, the 32nd needs the next
+//     lane's first byte -- one DPP move, no LDS -- and lane 63's comes from a scalar load of the dword behind the block;
+//   * addresses are a wave-uniform base in scalar registers plus a constant lane offset;
+//   * the loop only ever sees whole blocks that lie strictly inside the corpus, so every pair counts and no lane keeps a
+//     tally: a segment of i iterations issues i x 32,768 increments per workgroup.  The blocks that are left over at the
+//     end of the workgroup's range (less than one iteration of the workgroup, plus the corpus tail) go through
+//     pc_count_range as before.
+// Segments, checksum, snapshot / rollback and the slow recount are those of k_pair_count_u8 (a void segment is recounted
+// stripe by stripe with the sweeping loop).
+constexpr uint32_t kPcBlockBytes = kWave * 32u;                  // one wave, one iteration
+constexpr uint32_t kPcBlockVecs = kPcBlockBytes / 16u;
+constexpr int kPcWaves = kPcThreads / kWave;
+
+struct PcBlock { u32x4 a, b; uint32_t edge; };
+
+__device__ __forceinline__ PcBlock pc_block_issue(const MBPE_GLOBAL_AS char *stripe /* wave-uniform */, uint32_t it, uint32_t voff) {
+    PcBlock r;
+    const MBPE_GLOBAL_AS char *p = stripe + (uint64_t)it * kPcBlockBytes;
+    r.a = *(const MBPE_GLOBAL_AS u32x4 *)(p + voff);
+    r.b = *(const MBPE_GLOBAL_AS u32x4 *)(p + voff + 16u);
+    // (uniform address, constant address space: a scalar load)
+    r.edge = *(const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(p + kPcBlockBytes);
+    return r;
+}
+
+// iterations [it0, it1) of this wave's stripe; every pair that starts in them counts
+__device__ __attribute__((noinline)) void pc_fast_range(uint32_t *hist, const uint8_t *text, uint64_t stripe_byte0, uint32_t it0, uint32_t it1) {
+    if (it0 >= it1) return;
+    const MBPE_GLOBAL_AS char *stripe = (const MBPE_GLOBAL_AS char *)uniform_ptr(reinterpret_cast<uintptr_t>(text) + stripe_byte0);
+    const uint32_t voff = lane_id() * 32u;
+    uint32_t k0xffff;
+    asm volatile("s_mov_b32 %0, 0xffff" : "=s"(k0xffff));
+    PcBlock nxt = pc_block_issue(stripe, it0, voff);
+    for (uint32_t it = it0; it < it1; ++it) {
+        const PcBlock cur = nxt;
+        nxt = pc_block_issue(stripe, it + 1 < it1 ? it + 1 : it, voff);        // (unconditional: see pc_count_range)
+        const uint32_t w[9] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cur.b.z, cur.b.w,
+                               wave_from_next(cur.a.x, cur.edge)};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pc_lean_pairs(hist, w[i], w[i + 1], k0xffff);
+    }
+}
+
+// (out of line: inlined, the generic loops' registers spill the fast loop's)
+__device__ __attribute__((noinline)) void pc_slow_range(uint32_t *hist, uint32_t *bp, const uint8_t *text, uint64_t n,
+                                                        uint64_t n_full, uint64_t begin, uint64_t end) {
+    pc_count_range<false, 1, true>(hist, bp, text, nullptr, n, n_full, end, begin, end);
+    __syncthreads();
+    pc_sweep(hist, bp);
+    __syncthreads();
+}
+__device__ __attribute__((noinline)) uint32_t pc_generic_range(uint32_t *hist, uint32_t *bp, const uint8_t *text, uint64_t n,
+                                                               uint64_t n_full, uint64_t begin, uint64_t end) {
+    return pc_count_range<false, kPcVpl, false>(hist, bp, text, nullptr, n, n_full, end, begin, end);
+}
+
+__global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t *__restrict__ text, uint64_t n,
+                                                                   uint32_t *__restrict__ bp,
+                                                                   uint32_t *__restrict__ snap /* [gridDim.x][kPcWords] */) {
+    __shared__ uint32_t hist[kPcWords];
+    __shared__ unsigned long long red[48];
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kPcWords; w += kPcThreads) hist[w] = 0;
+    __syncthreads();
+
+    // the workgroup's range of full 16-byte vectors, as in k_pair_count_u8
+    constexpr uint64_t kIterVecs = (uint64_t)kPcThreads * kPcVpl;
+    static_assert(kIterVecs == (uint64_t)kPcWaves * kPcBlockVecs, "one fast iteration of the workgroup = one generic iteration");
+    const uint64_t n_full = n / 16;
+    uint64_t per = (n_full + gridDim.x - 1) / gridDim.x;
+    per = (per + kIterVecs - 1) / kIterVecs * kIterVecs;
+    const uint64_t v_begin = per * blockIdx.x;
+    uint64_t v_end = v_begin + per;
+    if (v_end > n_full) v_end = n_full;
+    uint4 *my_snap = reinterpret_cast<uint4 *>(snap + (size_t)blockIdx.x * kPcWords);
+
+    // fast iterations: whole iterations of the workgroup whose blocks -- and the 4 bytes behind each -- lie inside the
+    // corpus, so that every one of their pairs has a second byte
+    uint64_t fast = v_end > v_begin ? (v_end - v_begin) / kIterVecs : 0;
+    while (fast > 0 && (v_begin + fast * kIterVecs) * 16 + 4 > n) --fast;
+    const uint32_t F = (uint32_t)fast;                                   // per stripe
+    const uint32_t wave = threadIdx.x / kWave;
+    const uint64_t stripe_vec0 = v_begin + (uint64_t)wave * F * kPcBlockVecs;
+
+    unsigned long long resid = 0;          // decoded sum of the counters (uniform)
+    uint32_t seg_iters = kPcSeg0;
+    for (uint32_t seg = 0; seg < F;) {
+        const uint32_t seg_end = seg + seg_iters < F ? seg + seg_iters : F;
+        if (resid) {                       // something to lose: snapshot
+#pragma unroll
+            for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k)
+                my_snap[k * kPcThreads + threadIdx.x] = reinterpret_cast<const uint4 *>(hist)[k * kPcThreads + threadIdx.x];
+        }
+        pc_fast_range(hist, text, stripe_vec0 * 16, seg, seg_end);
+        __syncthreads();
+        PcCheck ck = pc_check(hist, (unsigned long long)(seg_end - seg) * 32ull, red);
+        if (ck.sum == resid + ck.issued) {
+            if (ck.max >= 0x2000u) {
+                pc_sweep(hist, bp);
+                __syncthreads();
+                ck = pc_check(hist, 0, red);
+            }
+            resid = ck.sum;
+            if (ck.max * 8u < 0x8000u && seg_iters * 8 <= kPcSegMax) seg_iters *= 8;
+            else if (ck.max * 2u < 0x8000u && seg_iters * 2 <= kPcSegMax) seg_iters *= 2;
+            else if (ck.max >= 0x8000u && seg_iters > 4) seg_iters /= 2;
+        } else {
+            // a counter wrapped: the segment is void.  Restore, and recount it stripe by stripe with sweeps
+#pragma unroll
+            for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k)
+                reinterpret_cast<uint4 *>(hist)[k * kPcThreads + threadIdx.x] =
+                    resid ? my_snap[k * kPcThreads + threadIdx.x] : make_uint4(0, 0, 0, 0);
+            __syncthreads();
+            for (uint32_t w = 0; w < (uint32_t)kPcWaves; ++w) {
+                const uint64_t sv = v_begin + (uint64_t)w * F * kPcBlockVecs;
+                const uint64_t b = sv + (uint64_t)seg * kPcBlockVecs, e = sv + (uint64_t)seg_end * kPcBlockVecs;
+                pc_slow_range(hist, bp, text, n, n_full, b, e);
+            }
+            resid = pc_check(hist, 0, red).sum;
+            seg_iters = seg_iters >= 32 ? seg_iters / 4 : 8;
+        }
+        seg = seg_end;
+    }
+    // what the fast iterations left of the workgroup's range: the generic loop, as one more segment
+    {
+        const uint64_t r_begin = v_begin + (uint64_t)F * kIterVecs;
+        if (r_begin < v_end) {
+            if (resid) {
+#pragma unroll
+                for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k)
+                    my_snap[k * kPcThreads + threadIdx.x] = reinterpret_cast<const uint4 *>(hist)[k * kPcThreads + threadIdx.x];
+            }
+            const uint32_t issued = pc_generic_range(hist, bp, text, n, n_full, r_begin, v_end);
+            __syncthreads();
+            const PcCheck ck = pc_check(hist, issued, red);
+            if (ck.sum != resid + ck.issued) {
+#pragma unroll
+                for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k)
+                    reinterpret_cast<uint4 *>(hist)[k * kPcThreads + threadIdx.x] =
+                        resid ? my_snap[k * kPcThreads + threadIdx.x] : make_uint4(0, 0, 0, 0);
+                __syncthreads();
+                pc_slow_range(hist, bp, text, n, n_full, r_begin, v_end);
+            }
+        }
+    }
+    __syncthreads();
+    pc_flush(hist, bp);
+    // ragged tail: pairs starting at byte 16*n_full - 1 .. n-2
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        uint64_t i = n_full * 16;
+        if (i > 0) --i;                      // the pair straddling into the tail
+        if (n_full * 16 == n) i = n;         // no tail at all
+        for (; i + 1 < n; ++i) atomicAdd(&bp[((uint32_t)text[i] << 8) | text[i + 1]], 1u);
     }
 }
 
@@ -1342,25 +1538,6 @@ struct TileIn {
     uint32_t smw;   // lanes 0..11: the 12 dwords of the summaries of tile-1, tile, tile+1 (lane = 4 * k + word)
 };
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// whole-wave shifts by one lane (DPP): lane i takes lane i+1 / lane i-1, the last / first lane takes `edge`
-__device__ __forceinline__ uint32_t wave_from_next(uint32_t v, uint32_t edge) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false);     // wave_shl:1
-}
-__device__ __forceinline__ uint32_t wave_from_prev(uint32_t v, uint32_t edge) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false);     // wave_shr:1
-}
-// this lane's bit of a wave mask, as a condition (one v_cndmask at the use, no 64-bit lane arithmetic)
-__device__ __forceinline__ bool lane_of(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
-
-#define MBPE_GLOBAL_AS __attribute__((address_space(1)))
-// a wave-uniform address, pinned to scalar registers
-__device__ __forceinline__ uintptr_t uniform_ptr(uintptr_t p) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
-    return ((uintptr_t)hi << 32) | lo;
-}
-
 // Both loads are unconditional: a branch around a load makes hipcc wait
 // vmcnt(0) at the next use, which would drain the tiles prefetched behind
 // this one.  The three summaries come through a bounds-checked buffer load of
@@ -1374,7 +1551,11 @@ __device__ __forceinline__ TileIn tile_issue(const uint16_t *tok, __amdgpu_buffe
     // (uniform 64-bit base + 32-bit lane offset: the address then needs one VGPR, not a pair per buffer)
     const MBPE_GLOBAL_AS char *base =
         (const MBPE_GLOBAL_AS char *)uniform_ptr(reinterpret_cast<uintptr_t>(tok) + (uint64_t)tile * (kWave * 16u));
+#if MBPE_NT_STREAM
+    const u32x4 q = __builtin_nontemporal_load((const MBPE_GLOBAL_AS u32x4 *)(base + lane * 16u));
+#else
     const u32x4 q = *(const MBPE_GLOBAL_AS u32x4 *)(base + lane * 16u);
+#endif
     t.q = make_uint4(q.x, q.y, q.z, q.w);
     const uint32_t j = tile + (lane >> 2) - 1u;                // tile 0, lanes 0..3 wrap to 0xFFFFFFFF
     const uint32_t off = (lane < 12 && j < 0x0FFFFFFFu) ? j * 16u + (lane & 3u) * 4u : 0xFFFFFFF0u;
@@ -3202,7 +3383,10 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
     };
     uint32_t lane = lane_id();
     asm volatile("" : "+v"(lane));
-    const uint32_t live = old_z & 0xFFFFu;       // uniform, >= 1
+    const uint32_t live = old_z & 0xFFFFu;       // uniform
+    // (an empty tile holds no match and stays as it is: k_rewrite_marked walks EVERY tile after an abandoned fused pass,
+    //  empty ones included, and `live - 1` below selects lanes and slots)
+    if (live == 0u) return q_orig;
     uint32_t tile_first = old_x & 0xFFFFu, tile_last = old_y >> 16;
     if (TT && renamed) {                 // (uniform, rare: s[] and h hold stand-in ids where tt_rename put them)
         const uint32_t li = live - 1u;
@@ -3559,7 +3743,11 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
         MBPE_GLOBAL_AS char *obase =
             (MBPE_GLOBAL_AS char *)uniform_ptr(reinterpret_cast<uintptr_t>(dst) + (uint64_t)tile * (kWave * 16u));
         u32x4 oq; oq.x = outq.x; oq.y = outq.y; oq.z = outq.z; oq.w = outq.w;
+#if MBPE_NT_STREAM
+        __builtin_nontemporal_store(oq, (MBPE_GLOBAL_AS u32x4 *)(obase + lane * 16u));
+#else
         *(MBPE_GLOBAL_AS u32x4 *)(obase + lane * 16u) = oq;
+#endif
 
         if (!v1) break;
         tile += n_waves;
@@ -4236,6 +4424,11 @@ __global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag, const BatchState
     ctl->fused = 0;
     ctl->marks_all = 0;
     if (ctl->commit_n) ctl->size_hist[31 - __builtin_clz(ctl->commit_n) > 7 ? 7 : 31 - __builtin_clz(ctl->commit_n)] += 1;
+    if (fused_flag) {              // ("time_kernels": live tokens after this sequence and the merges it committed)
+        fused_flag[1] = (uint32_t)ctl->n_live;
+        fused_flag[2] = (uint32_t)(ctl->n_live >> 32);
+        fused_flag[3] = ctl->commit_n;
+    }
     ctl->k_done += ctl->commit_n;
     ctl->batch_n = 0;
     ctl->commit_n = 0;
@@ -4520,16 +4713,18 @@ void launch_fill_u16(hipStream_t s, uint16_t *p, uint64_t n, uint16_t v) {
 size_t pair_count_scratch_bytes(int n_workgroups) { return (size_t)(n_workgroups < 1 ? 1 : n_workgroups) * kPcWords * 4; }
 
 void launch_pair_count_u8(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask,
-                          uint32_t *bp, int n_workgroups, uint32_t *scratch) {
+                          uint32_t *bp, int n_workgroups, uint32_t *scratch, hipEvent_t start, hipEvent_t stop) {
     if (n < 2) return;
     uint64_t n_vec = n / 16;
     uint64_t max_wg = (n_vec + kPcThreads * kPcVpl - 1) / (kPcThreads * kPcVpl);
     if ((uint64_t)n_workgroups > max_wg) n_workgroups = (int)max_wg;
     if (n_workgroups < 1) n_workgroups = 1;
     if (endmask)
-        hipLaunchKernelGGL(k_pair_count_u8<true>, dim3(n_workgroups), dim3(kPcThreads), 0, s, text, n, endmask, bp, scratch);
+        hipExtLaunchKernelGGL(k_pair_count_u8<true>, dim3(n_workgroups), dim3(kPcThreads), 0, s, start, stop, 0, text, n, endmask, bp, scratch);
+    else if (MBPE_PC_FAST)
+        hipExtLaunchKernelGGL(k_pair_count_u8_fast, dim3(n_workgroups), dim3(kPcThreads), 0, s, start, stop, 0, text, n, bp, scratch);
     else
-        hipLaunchKernelGGL(k_pair_count_u8<false>, dim3(n_workgroups), dim3(kPcThreads), 0, s, text, n, endmask, bp, scratch);
+        hipExtLaunchKernelGGL(k_pair_count_u8<false>, dim3(n_workgroups), dim3(kPcThreads), 0, s, start, stop, 0, text, n, endmask, bp, scratch);
 }
 
 void launch_widen(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask, uint16_t *tok,

@@ -248,8 +248,10 @@ void launch_fill_u16(hipStream_t s, uint16_t *p, uint64_t n, uint16_t v);
 // last byte of its chunk (NULL for a one-chunk corpus). bp[first<<8|second].
 // scratch: pair_count_scratch_bytes(n_workgroups) of device memory (per-workgroup histogram snapshots)
 size_t pair_count_scratch_bytes(int n_workgroups);
+// start / stop (optional): HIP events recorded at the beginning and the end of the dispatch itself
 void launch_pair_count_u8(hipStream_t s, const uint8_t *text, uint64_t n,
-                          const uint8_t *endmask, uint32_t *bp, int n_workgroups, uint32_t *scratch);
+                          const uint8_t *endmask, uint32_t *bp, int n_workgroups, uint32_t *scratch,
+                          hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 
 // u8 corpus -> 16-bit slot stream (+END flags), padded to whole tiles with holes
 void launch_widen(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask,
@@ -329,7 +331,8 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const 
                            uint32_t *chg, uint32_t *list /* [n_tiles] scratch */, const BatchState *bs, DevCtl *ctl,
                            const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus,
                            const uint32_t *run_in /* as for launch_merge: used when the batch has a (t,t) member */);
-// fused_flag (optional): set to 1 when this sequence ran the fused pass
+// fused_flag (optional, 4 words): [0] = 1 when this sequence ran the fused pass, [1..2] = live tokens of the shard after
+// the sequence, [3] = merges it committed
 void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag, const BatchState *bs);
 
 // compaction: exclusive scan of n_live over tiles, then scatter.  `offsets` needs

@@ -11,6 +11,7 @@
 // compaction of holes, growth of the pair table.
 #include "mbpe.h"
 #include "mbpe_dev.h"
+#include "wide.h"
 #include "../host/mbpe_host.h"
 
 #include <dlfcn.h>
@@ -224,6 +225,24 @@ struct mbpe_ctx {
     uint32_t *seq_flags = nullptr;  // per sequence of a group: 1 = a fused pass ran (opt_time_kernels)
     std::vector<uint32_t> h_seq_flags;
 
+    // 32-bit continuation of a training whose vocabulary lies beyond the 16-bit slot format (wide.h)
+    bool wide = false;               // this training hands over to the 32-bit loop after n_target merges
+    bool wide_active = false;        // ... and has done so
+    uint32_t vocab_total = 0;        // the caller's vocab_size (vocab_size is the 16-bit part's)
+    uint32_t n_target_total = 0;     // vocab_total - 256
+    int64_t opt_wide_from = -1;      // tests: hand over after this many merges whatever the vocabulary (-1: at the format's limit)
+    uint32_t *wtok[2] = {nullptr, nullptr};
+    int wcur = 0;
+    uint32_t *wval = nullptr, *wscratch = nullptr;
+    WideTable wtab = {};
+    WideCtl *wctl = nullptr;
+    WideBest *wbest = nullptr;
+    unsigned long long *warg = nullptr;
+    uint64_t wn_upper = 0;           // host-side upper bound of the stream length
+    uint32_t wk = 0;                 // merges of the wide loop known to the host
+    WideCtl h_wctl = {};
+    std::vector<WideBest> h_wbest;   // ... and what they were
+
     mbpe_stats stats = {};
 
     // Device buffers of a training run are kept when the run ends and handed out again to the next one that asks
@@ -309,6 +328,13 @@ void free_training(mbpe_ctx *c) {
     tfree(c, c->bp); tfree(c, c->ctl); tfree(c, c->best); tfree(c, c->xb); tfree(c, c->xb0);
     tfree(c, c->d_left); tfree(c, c->d_right); tfree(c, c->bs); tfree(c, c->sel); tfree(c, c->seq_flags); tfree(c, c->run_in);
     tfree(c, c->first_state);
+    tfree(c, c->wtok[0]); tfree(c, c->wtok[1]); tfree(c, c->wval); tfree(c, c->wscratch);
+    tfree(c, c->wtab.keys); tfree(c, c->wtab.cnts); tfree(c, c->wctl); tfree(c, c->wbest); tfree(c, c->warg);
+    c->wtab = {};
+    c->wide_active = false;
+    c->wk = 0;
+    c->wn_upper = 0;
+    c->h_wbest.clear();
     c->LR = nullptr;
     c->pending = 0;
     c->begun = false;
@@ -327,6 +353,7 @@ void free_corpus(mbpe_ctx *c) {
 static inline bool dense_possible(const mbpe_ctx *c) { return c->vocab_size <= 32768; }
 static inline bool use_dense(const mbpe_ctx *c) {
     if (!dense_possible(c)) return false;
+    if (c->wide) return false;           // (the conversion to the 32-bit loop reads the hashed layout's entry arrays)
     return c->opt_dense_table != 0;      // -1 (auto) and 1: dense whenever the vocabulary allows it
 }
 
@@ -518,6 +545,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "first_batches") c->opt_first_batches = value != 0;
     else if (n == "sel_cap") c->opt_sel_cap = std::min<int64_t>(std::max<int64_t>(64, value), kSelCap);
     else if (n == "byte_table") c->opt_byte_table = value != 0;
+    else if (n == "wide_from") c->opt_wide_from = value < 0 ? -1 : value;      // (read by the next mbpe_train_begin)
     else if (n == "pc_repeat") c->opt_pc_repeat = std::min<int64_t>(std::max<int64_t>(1, value), 1000);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
     return MBPE_OK;
@@ -678,10 +706,18 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
     // ("pc_repeat" > 1: that many launches back to back between the two events -- the kernel's sustained duration
     //  without one event marker's overhead per launch; the table then holds that multiple of every count)
     const int reps = table65536_out ? 1 : (int)std::max<int64_t>(1, c->opt_pc_repeat);
+    // (every dispatch also carries its own start / stop events -- hipExtLaunchKernelGGL -- so that the kernel's duration
+    //  is known without the gap between two launches or the cost of a marker: ms_pair_count_kernel)
+    while (c->kev.size() < 2ull * reps) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreate(&ev));
+        c->kev.push_back(ev);
+    }
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (!c->inert)
         for (int r = 0; r < reps; ++r)
-            launch_pair_count_u8(c->stream, c->d_text, c->n_bytes, c->d_endmask, bp, c->n_cus, c->pc_scratch);
+            launch_pair_count_u8(c->stream, c->d_text, c->n_bytes, c->d_endmask, bp, c->n_cus, c->pc_scratch,
+                                 c->kev[2 * r], c->kev[2 * r + 1]);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipGetLastError();
@@ -689,6 +725,16 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
     if (e != hipSuccess) { mbpe_host::set_last_error(hip_err("pair count", e)); return MBPE_ERR_HIP; }
     HIPCHK(hipEventElapsedTime(&c->stats.ms_pair_count, c->ev0, c->ev1));
     c->stats.ms_pair_count /= (float)reps;
+    c->stats.ms_pair_count_kernel = 0;
+    if (!c->inert && c->n_bytes >= 2) {
+        float sum = 0;
+        for (int r = 0; r < reps; ++r) {
+            float km = 0;
+            HIPCHK(hipEventElapsedTime(&km, c->kev[2 * r], c->kev[2 * r + 1]));
+            sum += km;
+        }
+        c->stats.ms_pair_count_kernel = sum / (float)reps;
+    }
     c->stats.pair_count_launches += (uint32_t)reps;
     return MBPE_OK;
 }
@@ -746,7 +792,10 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(tmalloc(c, &c->tile_list, ((size_t)c->n_tiles + 64) * 4));
     HIPCHK(hipMemsetAsync(c->chg, 0, ((size_t)c->n_tiles / 32 + 2) * 4, c->stream));
     HIPCHK(tmalloc(c, &c->offsets, ((size_t)c->n_tiles + tile_scan_scratch(c->n_tiles)) * 8));
-    const size_t xb_words = (size_t)c->hdr_words + c->hdrb_words + lr_words(vocab_size, kBatchMax) + 8;
+    // (the LR rows of the largest batch THIS training can select: seq_stage_a clamps every batch to max_batch_eff, so a
+    //  later, larger "max_batch" cannot reach beyond it.  2 x max_batch_eff x lr_pitch(vocab) words: 1.05 GB at the
+    //  defaults with vocab 32,000, 262 MB with several ranks or "max_batch" 1024)
+    const size_t xb_words = (size_t)c->hdr_words + c->hdrb_words + lr_words(vocab_size, c->max_batch_eff) + 8;
     const size_t xb0_words = 65536 + (size_t)c->hdr_words;
     HIPCHK(tmalloc(c, &c->xb, xb_words * 4));
     HIPCHK(tmalloc(c, &c->xb0, xb0_words * 4));
@@ -758,7 +807,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(tmalloc(c, &c->bs, sizeof(BatchState)));
     HIPCHK(tmalloc(c, &c->sel, sizeof(SelList)));
     HIPCHK(tmalloc(c, &c->run_in, ((size_t)c->n_tiles + 64) * 4));
-    HIPCHK(tmalloc(c, &c->seq_flags, 4096 * 4));
+    HIPCHK(tmalloc(c, &c->seq_flags, 4096 * 4 * 4));      // 4 words per sequence of a group (k_seq_finish)
     HIPCHK(hipMemsetAsync(c->bs, 0, sizeof(BatchState), c->stream));
     if (c->opt_first) {
         HIPCHK(tmalloc(c, &c->first_state, first_state_bytes()));
@@ -917,7 +966,7 @@ static inline bool use_batches(const mbpe_ctx *c) {
     return c->opt_multi_merge != 0 && (!c->opt_first || (c->opt_first_batches && !c->first_legacy));
 }
 
-static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exchange
+static int seq_stage_a(mbpe_ctx *c, int ev_slot) {       // up to the delta exchange
     const uint32_t endbit = endbit_of(c);
     const bool multi = is_multi(c);
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
@@ -927,7 +976,12 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
     if (c->opt_first)
         launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best, c->first_state, c->tok[0], c->tok[1], c->sums, c->n_tiles,
                               endbit, c->n_cus, 1);
-    if (multi) (void)seq_info_enqueue(c);
+    if (multi) {
+        // (a failed copy or event would leave the PREVIOUS sequence's sizes in h_seq: this rank would then exchange a
+        //  length its peers do not -- fail the call instead)
+        const int rc = seq_info_enqueue(c);
+        if (rc != MBPE_OK) return rc;
+    }
     if (ev_slot >= 0) (void)hipEventRecord(c->kev[2 * ev_slot], c->stream);
     // (the live token buffer is ctl->cur: a fused pass flips it without the host knowing)
     launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
@@ -941,6 +995,7 @@ static void seq_stage_a(mbpe_ctx *c, int ev_slot) {      // up to the delta exch
         (void)hipEventRecord(c->kev_f[2 * ev_slot + 1], c->stream);
         (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
     }
+    return MBPE_OK;
 }
 
 static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge exchange
@@ -958,7 +1013,7 @@ static void seq_stage_b(mbpe_ctx *c) {                   // up to the edge excha
     launch_rewrite_marked(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->tile_list, c->bs, c->ctl, le, re,
                           endbit, c->n_cus, c->run_in);
     launch_patch_sums(c->stream, c->best, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 1);
-    launch_seq_finish(c->stream, c->ctl, c->seq_slot >= 0 ? c->seq_flags + c->seq_slot : nullptr, c->bs);
+    launch_seq_finish(c->stream, c->ctl, c->seq_slot >= 0 ? c->seq_flags + 4 * c->seq_slot : nullptr, c->bs);
     if (multi)
         launch_rank_edge(c->stream, c->sums, c->n_tiles, reinterpret_cast<RankEdge *>(c->xb + 2) + c->rank, c->ctl,
                          c->xb);
@@ -1007,9 +1062,22 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     if (vocab_size < 256) { mbpe_host::set_last_error("vocab_size must be >= 256"); return MBPE_ERR_ARG; }
     const uint32_t vmax = !c->chunked ? MBPE_MAX_VOCAB_BASIC : c->opt_barrier == 0 ? MBPE_MAX_VOCAB_ENDBIT : MBPE_MAX_VOCAB_CHUNKED;
     c->barrier = c->chunked && (c->opt_barrier == 1 || (c->opt_barrier != 0 && vocab_size > MBPE_MAX_VOCAB_ENDBIT));
-    if (vocab_size > vmax) {
-        mbpe_host::set_last_error("vocab_size exceeds the 16-bit slot format (" + std::to_string(vmax) + ")");
-        return MBPE_ERR_VOCAB;
+    // Beyond the 16-bit slot format (Token is a uint32_t in the reference, Tokenizer.h:37-38) the training runs its first
+    // vmax - 256 merges on the slot stream and continues on 32-bit tokens (wide.h): lexical tie-break, one GPU.
+    const uint32_t total = vocab_size;
+    c->wide = false;
+    if (vocab_size > vmax || (c->opt_wide_from >= 0 && (int64_t)vocab_size - 256 > c->opt_wide_from)) {
+        if (vocab_size > MBPE_MAX_VOCAB_WIDE) {
+            mbpe_host::set_last_error("vocab_size exceeds " + std::to_string(MBPE_MAX_VOCAB_WIDE));
+            return MBPE_ERR_VOCAB;
+        }
+        if (c->opt_first || is_multi(c)) {
+            mbpe_host::set_last_error("vocab_size exceeds the 16-bit slot format (" + std::to_string(vmax) +
+                                      "): the 32-bit continuation is lexical tie-break on one GPU only");
+            return MBPE_ERR_VOCAB;
+        }
+        c->wide = true;
+        vocab_size = c->opt_wide_from >= 0 ? (uint32_t)std::min<int64_t>(256 + c->opt_wide_from, vmax) : vmax;
     }
     if (c->opt_first && (is_multi(c) || c->n_bytes + (c->barrier ? c->n_barriers : 0) >= 0xFFFFFE00ull)) {
         mbpe_host::set_last_error("conflict_resolution first: one GPU and a corpus below 4 GiB only");
@@ -1017,6 +1085,8 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
     }
     HIPCHK(hipSetDevice(c->device));
     int rc = begin_local(c, vocab_size);
+    c->vocab_total = total;
+    c->n_target_total = total - 256;
     if (rc != MBPE_OK) return rc;
     if (is_multi(c)) {
         if (c->comm_external) {
@@ -1060,6 +1130,7 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
         // (for THIS group: the "batch" / "max_batch" options may have changed since the bound was last computed)
         update_hot_possible(c, c->last_top, (uint64_t)group * kBatchMax);
         const uint32_t batches_before = c->h_ctl.n_batches, singles_before = c->h_ctl.cut_single;
+        unsigned long long live_prev = c->h_ctl.n_live;      // (exact: the host synchronised before this group)
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         uint32_t launched = 0;
         // (sequences past the target do nothing on the device -- ctl->k_limit -- but cost their launches: enqueue
@@ -1067,7 +1138,10 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
         //  needed if every one merged max_batch pairs)
         for (uint32_t g = 0; g < group && (c->merges_per_seq > 0 ? c->k + g * c->merges_per_seq < target : c->k_upper < target);
              ++g, ++launched) {
-            seq_stage_a(c, c->opt_time_kernels ? (int)g : -1);
+            {
+                const int rc = seq_stage_a(c, c->opt_time_kernels ? (int)g : -1);
+                if (rc != MBPE_OK) return rc;
+            }
             if (is_multi(c)) {
                 // (the selection's result arrives while the stream pass runs: every rank took the same decisions, so
                 //  the counts agree, and the all-reduce is enqueued long before the pass ends)
@@ -1096,19 +1170,23 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
         HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->stats.ms_steps += ms;
         if (c->opt_time_kernels) {
-            c->h_seq_flags.resize(launched);
+            c->h_seq_flags.resize(4 * (size_t)launched);
             if (launched)
-                HIPCHK(hipMemcpy(c->h_seq_flags.data(), c->seq_flags, launched * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(c->h_seq_flags.data(), c->seq_flags, launched * 16, hipMemcpyDeviceToHost));
             for (uint32_t g = 0; g < launched; ++g) {
                 float km = 0;
                 HIPCHK(hipEventElapsedTime(&km, c->kev[2 * g], c->kev[2 * g + 1]));
                 c->stats.ms_merge_kernel += km;
-                if (c->h_seq_flags[g]) {          // this sequence ran the fused pass
+                const unsigned long long live_after =
+                    ((unsigned long long)c->h_seq_flags[4 * g + 2] << 32) | c->h_seq_flags[4 * g + 1];
+                if (c->h_seq_flags[4 * g]) {      // this sequence ran the fused pass
                     HIPCHK(hipEventElapsedTime(&km, c->kev_f[2 * g], c->kev_f[2 * g + 1]));
                     c->stats.ms_fused_kernel += km;
                     c->stats.fused_launches++;
                     c->stats.fused_slots += c->n_slots;
+                    c->stats.fused_live_tokens += live_prev + live_after;
                 }
+                live_prev = live_after;
             }
             c->stats.merge_launches += c->h_ctl.n_batches - batches_before;   // sequences that did work
         }
@@ -1158,12 +1236,34 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
     return MBPE_OK;
 }
 
+static int train_steps16(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out);
+static int wide_convert(mbpe_ctx *c);
+static int wide_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *done_out);
+
 int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
     if (steps_done_out) *steps_done_out = 0;
     if (!c) return MBPE_ERR_ARG;
     if (!c->begun) { mbpe_host::set_last_error("mbpe_train_steps before mbpe_train_begin"); return MBPE_ERR_STATE; }
     if (c->pending) { mbpe_host::set_last_error("an exchange is pending: call mbpe_comm_exchange_done"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
+    if (!c->wide) return train_steps16(c, n_steps, steps_done_out);
+    // a training that continues on 32-bit tokens: the slot stream's share first, then the conversion, then the rest
+    uint32_t done = 0;
+    if (!c->wide_active) {
+        int rc = train_steps16(c, n_steps, &done);
+        if (steps_done_out) *steps_done_out = done;
+        if (rc != MBPE_OK || done >= n_steps || c->exhausted || c->k < c->n_target) return rc;
+        rc = wide_convert(c);
+        if (rc != MBPE_OK) return rc;
+    }
+    uint32_t more = 0;
+    int rc = wide_steps(c, n_steps - done, &more);
+    if (steps_done_out) *steps_done_out = done + more;
+    return rc;
+}
+
+static int train_steps16(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
+    if (steps_done_out) *steps_done_out = 0;
     if (is_multi(c) && c->comm_external) {
         // one sequence (or one merge) per round trip: local part now, the rest in mbpe_comm_exchange_done
         if (n_steps == 0 || c->k >= c->n_target || c->exhausted) return MBPE_OK;
@@ -1176,7 +1276,10 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
                 if (rc != MBPE_OK) return rc;
             }
             c->k_upper = c->k;
-            seq_stage_a(c, -1);
+            {
+                const int rc = seq_stage_a(c, -1);
+                if (rc != MBPE_OK) return rc;
+            }
             HIPCHK(hipStreamSynchronize(c->stream));
             c->pending = 3;
             return MBPE_NEED_EXCHANGE;
@@ -1269,6 +1372,139 @@ int mbpe_train_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out) {
     return MBPE_OK;
 }
 
+// ---- the 32-bit continuation (wide.h) ----------------------------------------------------------------------------
+
+static int wide_alloc_table(mbpe_ctx *c, WideTable *t, uint64_t want_entries) {
+    uint32_t bits = 12;
+    while ((1ull << bits) < 2 * want_entries && bits < 31) ++bits;
+    if ((1ull << bits) < 2 * want_entries) { mbpe_host::set_last_error("pair table beyond 2^30 entries"); return MBPE_ERR_OVERFLOW; }
+    *t = {};
+    t->mask = (uint32_t)((1ull << bits) - 1);
+    t->shift = 64 - bits;
+    HIPCHK(tmalloc(c, &t->keys, (size_t)8 << bits));
+    HIPCHK(tmalloc(c, &t->cnts, (size_t)4 << bits));
+    launch_wide_table_clear(c->stream, *t);
+    return MBPE_OK;
+}
+
+// entries `merges` merges can add at most when no count exceeds `top`: per match one (x,X) and one (X,y), per merge
+// possibly the transient (X,a) of touching matches; a merge has at most `top` matches
+static uint64_t wide_headroom(unsigned long long top, uint32_t merges) { return (uint64_t)merges * (2ull * top + 2); }
+
+static int wide_sync(mbpe_ctx *c) {
+    HIPCHK(hipMemcpyAsync(&c->h_wctl, c->wctl, sizeof(WideCtl), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    if (c->h_wctl.err) {
+        mbpe_host::set_last_error("device error: the 32-bit pair table is full");
+        return MBPE_ERR_OVERFLOW;
+    }
+    return MBPE_OK;
+}
+
+// slot stream + hashed pair table of the 16-bit part -> 32-bit tokens + 64-bit-key table.  From here on the training's
+// stream, table and merge counter live in the w* members; the 16-bit buffers go back to the pool.
+static int wide_convert(mbpe_ctx *c) {
+    int rc = sync_ctl(c);
+    if (rc != MBPE_OK) return rc;
+    rc = do_compact(c);                       // no holes left: the first n_live slots are the stream (barriers included)
+    if (rc != MBPE_OK) return rc;
+    const uint64_t n_live_slots = c->h_ctl.n_live;
+    const uint64_t n_tok = n_live_slots - (c->barrier ? c->n_barriers : 0);
+    const uint32_t n_wide = c->n_target_total - c->n_target;
+    HIPCHK(tmalloc(c, &c->wtok[0], std::max<uint64_t>(n_tok, 1) * 4));
+    HIPCHK(tmalloc(c, &c->wtok[1], std::max<uint64_t>(n_tok, 1) * 4));
+    HIPCHK(tmalloc(c, &c->wval, std::max<uint64_t>(n_live_slots, 1) * 4));
+    HIPCHK(tmalloc(c, &c->wscratch, wide_scratch_words(n_live_slots) * 4));
+    HIPCHK(tmalloc(c, &c->wctl, sizeof(WideCtl)));
+    HIPCHK(tmalloc(c, &c->wbest, ((size_t)n_wide + 2) * sizeof(WideBest)));
+    HIPCHK(tmalloc(c, &c->warg, 2 * 1024 * 8));
+    HIPCHK(hipMemsetAsync(c->wctl, 0, sizeof(WideCtl), c->stream));
+    const uint32_t barrier = c->barrier ? kBarrier : 0xFFFFFFFFu;
+    const uint32_t endbit = c->chunked && !c->barrier ? kEndBit : 0u;
+    launch_wide_from_slots(c->stream, c->tok[c->cur], n_live_slots, barrier, endbit, c->wval, c->wscratch, c->wtok[0], c->wctl);
+    c->wcur = 0;
+    unsigned long long top = c->last_top == ~0ull ? n_tok : c->last_top;
+    rc = wide_alloc_table(c, &c->wtab, (uint64_t)c->h_ctl.n_entries + wide_headroom(top, 16));
+    if (rc != MBPE_OK) return rc;
+    launch_wide_table_from16(c->stream, c->tab.ekey, c->tab.ecnt, c->h_ctl.n_entries, c->wtab, c->wctl);
+    rc = wide_sync(c);
+    if (rc != MBPE_OK) return rc;
+    if (c->h_wctl.n != n_tok || c->h_wctl.n_entries != c->h_ctl.n_entries) {
+        mbpe_host::set_last_error("conversion to 32-bit tokens lost tokens or pairs");
+        return MBPE_ERR_OVERFLOW;
+    }
+    c->wn_upper = n_tok;
+    c->wk = 0;
+    c->h_wbest.clear();
+    c->wide_active = true;
+    // the 16-bit stream and table are done with (their merges stay in best[])
+    tfree(c, c->tok[0]); tfree(c, c->tok[1]); tfree(c, c->sums); tfree(c, c->side); tfree(c, c->chg); tfree(c, c->tile_list);
+    tfree(c, c->offsets); tfree(c, c->run_in); tfree(c, c->xb);
+    tfree(c, c->tab.hslot); tfree(c, c->tab.ekey); tfree(c, c->tab.ecnt); tfree(c, c->tab.bmax); tfree(c, c->tab.smax);
+    c->LR = nullptr;
+    pool_trim(c);
+    return MBPE_OK;
+}
+
+static int wide_steps(mbpe_ctx *c, uint32_t n_steps, uint32_t *done_out) {
+    *done_out = 0;
+    const uint32_t n_wide = c->n_target_total - c->n_target;
+    uint32_t done = 0;
+    unsigned long long top = c->h_wbest.empty() ? (c->last_top == ~0ull ? c->wn_upper : c->last_top)
+                                                : (unsigned long long)c->h_wbest.back().count;
+    while (done < n_steps && c->wk < n_wide) {
+        const uint32_t group = std::min<uint32_t>({16u, n_steps - done, n_wide - c->wk});
+        // room for what this group can insert (load factor 1/2 at most)
+        if (2 * ((uint64_t)c->h_wctl.n_entries + wide_headroom(top, group)) > (uint64_t)c->wtab.mask + 1) {
+            WideTable old = c->wtab;
+            int rc = wide_alloc_table(c, &c->wtab, 2 * ((uint64_t)c->h_wctl.n_entries + wide_headroom(top, group)));
+            if (rc != MBPE_OK) return rc;
+            HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->wctl->n_entries), 0, 1, c->stream));
+            launch_wide_rehash(c->stream, old, c->wtab, c->wctl);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            trelease(c, old.keys); trelease(c, old.cnts);
+            c->stats.n_table_grows++;
+        }
+        HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->wctl->k_limit), (int)(c->wk + group), 1, c->stream));
+        HIPCHK(hipEventRecord(c->ev0, c->stream));
+        for (uint32_t g = 0; g < group; ++g) {
+            launch_wide_argmax(c->stream, c->wtab, c->wctl, c->wbest, c->warg);
+            launch_wide_merge(c->stream, c->wtok[c->wcur ^ (g & 1)], c->wtok[c->wcur ^ (g & 1) ^ 1], c->wn_upper, c->wval,
+                              c->wscratch, c->wtab, c->wctl, 256 + c->n_target);
+        }
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        int rc = wide_sync(c);
+        if (rc != MBPE_OK) return rc;
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->stats.ms_steps += ms;
+        const uint32_t ran = c->h_wctl.k - c->wk;
+        if (ran == 0) break;                    // empty table (Tokenizer.h:586-588): cannot happen after a 16-bit part that merged
+        c->h_wbest.resize((size_t)c->wk + ran);
+        HIPCHK(hipMemcpy(c->h_wbest.data() + c->wk, c->wbest + c->wk, (size_t)ran * sizeof(WideBest), hipMemcpyDeviceToHost));
+        c->wcur ^= (int)(ran & 1u);
+        c->wn_upper = c->h_wctl.n;
+        c->wk += ran;
+        done += ran;
+        top = (unsigned long long)std::max(0, c->h_wbest.back().count);
+        if (c->h_wbest.back().count == 0 && done < n_steps && c->wk < n_wide) {
+            // The best pair no longer occurs anywhere: merging it changes nothing, the reference chooses it again and
+            // again (never-erased table, PairCount.h:249-260; the loop only ends on an empty table, Tokenizer.h:586-588)
+            const uint32_t fill = std::min<uint32_t>(n_steps - done, n_wide - c->wk);
+            c->h_wbest.resize((size_t)c->wk + fill, c->h_wbest.back());
+            c->wk += fill;
+            done += fill;
+            HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->wctl->k), (int)c->wk, 1, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->h_wctl.k = c->wk;
+        }
+        if (ran < group) break;
+    }
+    *done_out = done;
+    return MBPE_OK;
+}
+
 int mbpe_train_sequences(mbpe_ctx *c, uint32_t n_sequences, uint32_t *merges_done_out) {
     if (merges_done_out) *merges_done_out = 0;
     if (!c) return MBPE_ERR_ARG;
@@ -1277,6 +1513,8 @@ int mbpe_train_sequences(mbpe_ctx *c, uint32_t n_sequences, uint32_t *merges_don
         mbpe_host::set_last_error("mbpe_train_sequences: not available with an external transport (use mbpe_train_steps)");
         return MBPE_ERR_STATE;
     }
+    if (c->wide_active || (c->wide && c->k >= c->n_target))
+        return mbpe_train_steps(c, n_sequences, merges_done_out);                    // (32-bit loop: one merge per pass)
     if (!use_batches(c)) return mbpe_train_steps(c, n_sequences, merges_done_out);   // one merge per pass
     HIPCHK(hipSetDevice(c->device));
     return train_steps_batched(c, c->n_target, merges_done_out, n_sequences);
@@ -1351,7 +1589,8 @@ int mbpe_comm_exchange_done(mbpe_ctx *c) {
                 if (rc != MBPE_OK) return rc;
             }
             c->k_upper = c->k;
-            seq_stage_a(c, -1);
+            rc = seq_stage_a(c, -1);
+            if (rc != MBPE_OK) return rc;
             HIPCHK(hipStreamSynchronize(c->stream));
             c->pending = 3;
             return MBPE_NEED_EXCHANGE;
@@ -1377,14 +1616,20 @@ int mbpe_train_result(mbpe_ctx *c, uint32_t *merges_out, int32_t *counts_out, ui
         while (real < n && (h[real] >> 32) != 0) ++real;
         n = real;
     }
-    if (n_merges_out) *n_merges_out = n;
-    if (n > cap_merges && merges_out) { mbpe_host::set_last_error("merges_out too small"); return MBPE_ERR_ARG; }
-    if (!n || !merges_out) return MBPE_OK;
+    const uint32_t nw = c->wide_active ? (uint32_t)c->h_wbest.size() : 0u;      // merges of the 32-bit continuation
+    if (n_merges_out) *n_merges_out = n + nw;
+    if (n + nw > cap_merges && merges_out) { mbpe_host::set_last_error("merges_out too small"); return MBPE_ERR_ARG; }
+    if (!(n + nw) || !merges_out) return MBPE_OK;
     for (uint32_t i = 0; i < n; ++i) {
         uint32_t key = ~(uint32_t)h[i];
         merges_out[2 * i] = key >> 16;
         merges_out[2 * i + 1] = key & 0xFFFFu;
         if (counts_out) counts_out[i] = (int32_t)(h[i] >> 32);
+    }
+    for (uint32_t i = 0; i < nw; ++i) {
+        merges_out[2 * (n + i)] = c->h_wbest[i].first;
+        merges_out[2 * (n + i) + 1] = c->h_wbest[i].second;
+        if (counts_out) counts_out[n + i] = c->h_wbest[i].count;
     }
     return MBPE_OK;
 }
@@ -1410,6 +1655,13 @@ int mbpe_get_stats(mbpe_ctx *c, mbpe_stats *out) {
     for (int i = 0; i < 8; ++i) c->stats.size_hist[i] = c->begun ? c->h_ctl.size_hist[i] : 0;
     c->stats.n_skipped = c->begun ? c->h_ctl.n_skipped : 0;
     c->stats.n_skip_cut = c->begun ? c->h_ctl.n_skip_cut : 0;
+    if (c->begun && c->wide_active) {          // the stream and the table are the 32-bit ones now
+        c->stats.n_slots = c->h_wctl.n;
+        c->stats.n_live = c->h_wctl.n;
+        c->stats.n_merges += (uint32_t)c->h_wbest.size();
+        c->stats.n_pairs = c->h_wctl.n_entries;
+        c->stats.n_batches += c->wk;            // (one stream pass per merge)
+    }
     *out = c->stats;
     return MBPE_OK;
 }
@@ -1446,6 +1698,19 @@ int mbpe_get_stream(mbpe_ctx *c, uint32_t *tokens_out, uint8_t *chunk_end_out, u
     if (!c->begun) { mbpe_host::set_last_error("mbpe_get_stream before mbpe_train_begin"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->wide_active) {
+        const uint64_t n = c->h_wctl.n;
+        *n_out = n;
+        if (!tokens_out) return MBPE_OK;
+        if (cap < n) { mbpe_host::set_last_error("tokens_out too small"); return MBPE_ERR_ARG; }
+        if (n) HIPCHK(hipMemcpy(tokens_out, c->wtok[c->wcur], n * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) {
+            // (a one-chunk corpus reports no chunk ends, like the slot stream)
+            if (chunk_end_out) chunk_end_out[i] = c->chunked ? (uint8_t)(tokens_out[i] >> 31) : 0;
+            tokens_out[i] &= kWideIdMask;
+        }
+        return MBPE_OK;
+    }
     std::vector<uint16_t> h(c->n_slots);
     HIPCHK(hipMemcpy(h.data(), c->tok[c->cur], c->n_slots * 2, hipMemcpyDeviceToHost));
     const bool endflag = c->chunked && !c->barrier;
@@ -1473,6 +1738,15 @@ int mbpe_stream_device(mbpe_ctx *c, const void **slots_out, uint64_t *n_slots_ou
     if (!c || !slots_out || !n_slots_out) return MBPE_ERR_ARG;
     if (!c->begun) { mbpe_host::set_last_error("mbpe_stream_device before mbpe_train_begin"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
+    if (c->wide_active) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *slots_out = c->wtok[c->wcur];
+        *n_slots_out = c->h_wctl.n;
+        if (slot_bits_out) *slot_bits_out = 32;
+        if (end_bit_out) *end_bit_out = kWideEnd;
+        if (barrier_out) *barrier_out = MBPE_NO_BARRIER;
+        return MBPE_OK;
+    }
     int rc = sync_ctl(c);          // also refreshes which of the two buffers is live
     if (rc != MBPE_OK) return rc;
     *slots_out = c->tok[c->cur];
@@ -1487,6 +1761,7 @@ int mbpe_table_device(mbpe_ctx *c, const void **cells_out, uint32_t *vshift_out)
     if (!c || !cells_out || !vshift_out) return MBPE_ERR_ARG;
     if (!c->begun) { mbpe_host::set_last_error("mbpe_table_device before mbpe_train_begin"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
+    if (c->wide_active) { mbpe_host::set_last_error("the pair table is hashed (no dense view)"); return MBPE_ERR_STATE; }
     int rc = sync_ctl(c);
     if (rc != MBPE_OK) return rc;
     if (!c->tab.cells) { mbpe_host::set_last_error("the pair table is hashed (no dense view)"); return MBPE_ERR_STATE; }
@@ -1500,6 +1775,28 @@ int mbpe_get_pairs(mbpe_ctx *c, uint32_t *first_out, uint32_t *second_out, int32
     if (!c || !n_out) return MBPE_ERR_ARG;
     if (!c->begun) { mbpe_host::set_last_error("mbpe_get_pairs before mbpe_train_begin"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
+    if (c->wide_active) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const uint64_t n = c->h_wctl.n_entries, slots = (uint64_t)c->wtab.mask + 1;
+        *n_out = n;
+        if (!first_out) return MBPE_OK;
+        if (cap < n) { mbpe_host::set_last_error("pair arrays too small"); return MBPE_ERR_ARG; }
+        std::vector<unsigned long long> keys(slots);
+        std::vector<int32_t> cnts(slots);
+        HIPCHK(hipMemcpy(keys.data(), c->wtab.keys, slots * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(cnts.data(), c->wtab.cnts, slots * 4, hipMemcpyDeviceToHost));
+        uint64_t o = 0;
+        for (uint64_t i = 0; i < slots; ++i) {
+            if (keys[i] == kWideEmpty) continue;
+            if (o >= n) { mbpe_host::set_last_error("pair table holds more pairs than counted"); return MBPE_ERR_OVERFLOW; }
+            first_out[o] = (uint32_t)(keys[i] >> 32);
+            second_out[o] = (uint32_t)keys[i];
+            if (count_out) count_out[o] = cnts[i];
+            ++o;
+        }
+        if (o != n) { mbpe_host::set_last_error("pair table holds fewer pairs than counted"); return MBPE_ERR_OVERFLOW; }
+        return MBPE_OK;
+    }
     int rc = sync_ctl(c);
     if (rc != MBPE_OK) return rc;
     const uint64_t n = c->h_ctl.n_entries;
@@ -1552,6 +1849,7 @@ int mbpe_compact(mbpe_ctx *c) {
     if (!c) return MBPE_ERR_ARG;
     if (!c->begun) { mbpe_host::set_last_error("mbpe_compact before mbpe_train_begin"); return MBPE_ERR_STATE; }
     HIPCHK(hipSetDevice(c->device));
+    if (c->wide_active) return MBPE_OK;        // (the 32-bit stream has no holes)
     int rc = sync_ctl(c);
     if (rc != MBPE_OK) return rc;
     return do_compact(c);

@@ -51,6 +51,7 @@ class Stats(ctypes.Structure):
         ("n_sel_retry", ctypes.c_uint32), ("adapt_limit", ctypes.c_uint32), ("n_sel_blocks", ctypes.c_uint64), ("size_hist", ctypes.c_uint32 * 8),
         ("n_skipped", ctypes.c_uint32), ("n_skip_cut", ctypes.c_uint32),
         ("exchange_words", ctypes.c_uint64), ("exchanges", ctypes.c_uint32), ("pad_", ctypes.c_uint32),
+        ("fused_live_tokens", ctypes.c_uint64), ("ms_pair_count_kernel", ctypes.c_float), ("pad2_", ctypes.c_uint32),
     ]
 
     def as_dict(self):

@@ -45,6 +45,8 @@ def live_tokens(tr, torch, device, lo=0, hi=None):
         ends[:-1] = is_bar[1:]
         keep = ~is_bar
         return raw[keep], ends[keep]
+    if end_bit and bits == 32:          # (the 32-bit continuation: bit 31 = last token of its chunk)
+        return raw & 0x7FFFFFFF, raw < 0
     if end_bit:
         return raw & ~end_bit, (raw & end_bit) != 0
     return raw, None
@@ -128,6 +130,8 @@ def tiles_in_prefix_form(tr, torch, device, slots_per_piece=1 << 28):
     """Every 512-slot tile of the stream holds its live tokens in its first slots and its holes behind them: what the
     stream kernels keep whenever they rewrite a tile (tile_compact in csrc/kernels.hip) and the fused pass relies on."""
     ptr, n_slots, bits, end_bit, barrier = tr.stream_device()
+    if bits == 32:
+        return True          # (the 32-bit continuation compacts its stream at every merge: no holes, no tiles)
     assert bits == 16 and n_slots % 512 == 0
     for lo in range(0, n_slots, slots_per_piece):
         hi = min(lo + slots_per_piece, n_slots)

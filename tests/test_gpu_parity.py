@@ -255,7 +255,8 @@ def test_train_tiny_inputs(tr, data, vocab):
 
 
 DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 4096, "fused_min": 24, "hier_argmax": -1,
-            "dense_table": -1, "threshold_select": 1, "sel_cap": 8192, "chunk_barrier": -1, "first_batches": 0, "byte_table": 1}
+            "dense_table": -1, "threshold_select": 1, "sel_cap": 8192, "chunk_barrier": -1, "first_batches": 0, "byte_table": 1,
+            "wide_from": -1}
 
 
 def _defaults(tr):
@@ -373,8 +374,16 @@ def test_vocab_limits(tr):
         tr.train_begin(255)
     assert e.value.code == mbpe.ERR_ARG
     with pytest.raises(mbpe.MbpeError) as e:
-        tr.train_begin(65535)
+        tr.train_begin((1 << 24) + 1)           # beyond MBPE_MAX_VOCAB_WIDE
     assert e.value.code == mbpe.ERR_VOCAB
+    tr.set_option("conflict_resolution", 0)     # the 32-bit continuation is lexical only
+    try:
+        with pytest.raises(mbpe.MbpeError) as e:
+            tr.train_begin(65535)
+        assert e.value.code == mbpe.ERR_VOCAB
+    finally:
+        tr.set_option("conflict_resolution", 1)
+    tr.train_begin(65535)                       # lexical: trains (tests/test_gpu_wide.py)
     # (chunked corpora: tests/test_gpu_barrier.py)
 
 
