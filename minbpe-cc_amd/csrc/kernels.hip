@@ -347,6 +347,10 @@ constexpr uint32_t kPcSegMax = 4096;
 #ifndef MBPE_PC_FAST
 #define MBPE_PC_FAST 1
 #endif
+// the final flush adds two bins per 64-bit atomic (0: one 32-bit atomic per bin, A/B)
+#ifndef MBPE_PC_FLUSH64
+#define MBPE_PC_FLUSH64 1
+#endif
 
 __device__ __forceinline__ uint32_t pc_table_index(uint32_t hbin) {
 #ifndef MBPE_PC_NOHASH
@@ -380,8 +384,29 @@ __device__ __forceinline__ void pc_sweep(uint32_t *hist, uint32_t *bp) {
 }
 
 // final flush: lanes walk consecutive OUTPUT indices so the global atomics of
-// a wave are contiguous (the LDS reads are bank-conflicted, but this runs once)
+// a wave are contiguous (the LDS reads are bank-conflicted, but this runs once).
+// Two bins per lane and ONE 64-bit atomic for both: the flush is 65,536 x 256 atomic lanes on one 256-KiB table, which the
+// memory side takes at a fixed rate of wave instructions (0.115 ms of a 4 GiB scan's 0.98 ms did not scale with the
+// corpus: most of it this) -- half as many instructions.  (No carry can run from the low bin into the high one: a pair
+// count stays below 2^31, k_table_init checks.)
 __device__ __forceinline__ void pc_flush(const uint32_t *hist, uint32_t *bp) {
+#if MBPE_PC_FLUSH64
+    unsigned long long *bp64 = reinterpret_cast<unsigned long long *>(bp);
+    for (uint32_t o2 = threadIdx.x; o2 < 32768u; o2 += kPcThreads) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; ++h) {
+            const uint32_t o = 2u * o2 + h;
+            uint32_t bin = ((o & 0xFFu) << 8) | (o >> 8);
+#ifndef MBPE_PC_NOHASH
+            bin ^= bin >> 8;
+#endif
+            const uint32_t c = (hist[bin & 0x7FFFu] >> ((bin >> 15) * 16)) & 0xFFFFu;
+            v |= (unsigned long long)c << (32u * h);
+        }
+        if (v) atomicAdd(&bp64[o2], v);
+    }
+#else
     for (uint32_t o = threadIdx.x; o < 65536u; o += kPcThreads) {
         uint32_t bin = ((o & 0xFFu) << 8) | (o >> 8);
 #ifndef MBPE_PC_NOHASH
@@ -390,6 +415,7 @@ __device__ __forceinline__ void pc_flush(const uint32_t *hist, uint32_t *bp) {
         const uint32_t c = (hist[bin & 0x7FFFu] >> ((bin >> 15) * 16)) & 0xFFFFu;
         if (c) atomicAdd(&bp[o], c);
     }
+#endif
 }
 
 // workgroup-wide: decoded sum of all counters + `issued` summed over the threads, and the largest counter
@@ -630,25 +656,31 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8(const uint8_t *__r
 // pc_lean_pairs on register data 0.89 ms.  k_pair_count_u8 ran at 1.05 ms because of what surrounds them: per vector a
 // 64-bit clamped address, a byte load for lane 63's straddling pair, a ds_bpermute for the other lanes' (an LDS
 // instruction itself) and the bookkeeping of which pairs count -- 6.7 vector instructions per pair all told.  Here
-//   * every WAVE owns a contiguous stripe of its workgroup's range and walks it in 2-KiB blocks, lane l holding bytes
-//     [32 l, 32 l + 32) of the block (two 16-byte loads): 31 of its 32 pairs lie inside the lane, the 32nd needs the next
-//     lane's first byte -- one DPP move, no LDS -- and lane 63's comes from a scalar load of the dword behind the block;
+//   * the workgroup walks its range in iterations of 16 consecutive 2-KiB blocks, one per WAVE, lane l holding bytes
+//     [32 l, 32 l + 32) of its wave's block (two 16-byte loads): 31 of its 32 pairs lie inside the lane, the 32nd needs the
+//     next lane's first byte -- one DPP move, no LDS -- and lane 63's comes from a load of the dword behind the block;
 //   * addresses are a wave-uniform base in scalar registers plus a constant lane offset;
 //   * the loop only ever sees whole blocks that lie strictly inside the corpus, so every pair counts and no lane keeps a
 //     tally: a segment of i iterations issues i x 32,768 increments per workgroup.  The blocks that are left over at the
 //     end of the workgroup's range (less than one iteration of the workgroup, plus the corpus tail) go through
 //     pc_count_range as before.
-// Segments, checksum, snapshot / rollback and the slow recount are those of k_pair_count_u8 (a void segment is recounted
-// stripe by stripe with the sweeping loop).
+// Segments, checksum, snapshot / rollback and the slow recount are those of k_pair_count_u8.
 constexpr uint32_t kPcBlockBytes = kWave * 32u;                  // one wave, one iteration
 constexpr uint32_t kPcBlockVecs = kPcBlockBytes / 16u;
 constexpr int kPcWaves = kPcThreads / kWave;
 
 struct PcBlock { u32x4 a, b; uint32_t edge; };
+#ifndef MBPE_PC_DEPTH
+#define MBPE_PC_DEPTH 1
+#endif
+constexpr int kPcDepth = MBPE_PC_DEPTH;
 
 __device__ __forceinline__ PcBlock pc_block_issue(const MBPE_GLOBAL_AS char *stripe /* wave-uniform */, uint32_t it, uint32_t voff) {
     PcBlock r;
-    const MBPE_GLOBAL_AS char *p = stripe + (uint64_t)it * kPcBlockBytes;
+    // (iteration `it` of the workgroup is 16 consecutive blocks, one per wave: the workgroup walks its range front to
+    //  back.  A contiguous stripe per wave -- 4,096 streams a mebibyte apart chip-wide -- started every launch with
+    //  ~40 us of page walks: its first 64 iterations took 2.25 us each instead of 1.7)
+    const MBPE_GLOBAL_AS char *p = stripe + (uint64_t)it * (kPcBlockBytes * (uint32_t)kPcWaves);
     r.a = *(const MBPE_GLOBAL_AS u32x4 *)(p + voff);
     r.b = *(const MBPE_GLOBAL_AS u32x4 *)(p + voff + 16u);
     // (uniform address, constant address space: a scalar load)
@@ -656,17 +688,23 @@ __device__ __forceinline__ PcBlock pc_block_issue(const MBPE_GLOBAL_AS char *str
     return r;
 }
 
-// iterations [it0, it1) of this wave's stripe; every pair that starts in them counts
+// iterations [it0, it1) of the workgroup, this wave's block of each; every pair that starts in them counts
 __device__ __attribute__((noinline)) void pc_fast_range(uint32_t *hist, const uint8_t *text, uint64_t stripe_byte0, uint32_t it0, uint32_t it1) {
     if (it0 >= it1) return;
     const MBPE_GLOBAL_AS char *stripe = (const MBPE_GLOBAL_AS char *)uniform_ptr(reinterpret_cast<uintptr_t>(text) + stripe_byte0);
     const uint32_t voff = lane_id() * 32u;
     uint32_t k0xffff;
     asm volatile("s_mov_b32 %0, 0xffff" : "=s"(k0xffff));
-    PcBlock nxt = pc_block_issue(stripe, it0, voff);
+    // kPcDepth blocks are in flight behind the one being counted (9 registers each)
+    const uint32_t last = it1 - 1u;
+    PcBlock ring[kPcDepth];
+#pragma unroll
+    for (int d = 0; d < kPcDepth; ++d) ring[d] = pc_block_issue(stripe, it0 + d < last ? it0 + d : last, voff);
     for (uint32_t it = it0; it < it1; ++it) {
-        const PcBlock cur = nxt;
-        nxt = pc_block_issue(stripe, it + 1 < it1 ? it + 1 : it, voff);        // (unconditional: see pc_count_range)
+        const PcBlock cur = ring[0];
+#pragma unroll
+        for (int d = 0; d + 1 < kPcDepth; ++d) ring[d] = ring[d + 1];
+        ring[kPcDepth - 1] = pc_block_issue(stripe, it + kPcDepth < last ? it + kPcDepth : last, voff);   // (unconditional: see pc_count_range)
         const uint32_t w[9] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cur.b.z, cur.b.w,
                                wave_from_next(cur.a.x, cur.edge)};
 #pragma unroll
@@ -692,6 +730,15 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t
                                                                    uint32_t *__restrict__ snap /* [gridDim.x][kPcWords] */) {
     __shared__ uint32_t hist[kPcWords];
     __shared__ unsigned long long red[48];
+#ifdef MBPE_PC_STAMPS
+    // diagnostic build: wall-clock stamps (100 MHz) of this workgroup's phases behind the snapshots: 16 x u64 per workgroup
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(snap + (size_t)gridDim.x * kPcWords) + 16 * blockIdx.x;
+    uint32_t n_stamp = 0;
+#define PC_STAMP() do { if (threadIdx.x == 0 && n_stamp < 16) stamps[n_stamp++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PC_STAMP() do {} while (0)
+#endif
+    PC_STAMP();
     for (uint32_t w = threadIdx.x; w < (uint32_t)kPcWords; w += kPcThreads) hist[w] = 0;
     __syncthreads();
 
@@ -710,9 +757,9 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t
     // corpus, so that every one of their pairs has a second byte
     uint64_t fast = v_end > v_begin ? (v_end - v_begin) / kIterVecs : 0;
     while (fast > 0 && (v_begin + fast * kIterVecs) * 16 + 4 > n) --fast;
-    const uint32_t F = (uint32_t)fast;                                   // per stripe
+    const uint32_t F = (uint32_t)fast;
     const uint32_t wave = threadIdx.x / kWave;
-    const uint64_t stripe_vec0 = v_begin + (uint64_t)wave * F * kPcBlockVecs;
+    const uint64_t stripe_vec0 = v_begin + (uint64_t)wave * kPcBlockVecs;     // this wave's block of iteration 0
 
     unsigned long long resid = 0;          // decoded sum of the counters (uniform)
     uint32_t seg_iters = kPcSeg0;
@@ -723,8 +770,10 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t
             for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k)
                 my_snap[k * kPcThreads + threadIdx.x] = reinterpret_cast<const uint4 *>(hist)[k * kPcThreads + threadIdx.x];
         }
+        PC_STAMP();
         pc_fast_range(hist, text, stripe_vec0 * 16, seg, seg_end);
         __syncthreads();
+        PC_STAMP();
         PcCheck ck = pc_check(hist, (unsigned long long)(seg_end - seg) * 32ull, red);
         if (ck.sum == resid + ck.issued) {
             if (ck.max >= 0x2000u) {
@@ -737,17 +786,13 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t
             else if (ck.max * 2u < 0x8000u && seg_iters * 2 <= kPcSegMax) seg_iters *= 2;
             else if (ck.max >= 0x8000u && seg_iters > 4) seg_iters /= 2;
         } else {
-            // a counter wrapped: the segment is void.  Restore, and recount it stripe by stripe with sweeps
+            // a counter wrapped: the segment is void.  Restore, and recount it with sweeps
 #pragma unroll
             for (int k = 0; k < kPcWords / 4 / kPcThreads; ++k)
                 reinterpret_cast<uint4 *>(hist)[k * kPcThreads + threadIdx.x] =
                     resid ? my_snap[k * kPcThreads + threadIdx.x] : make_uint4(0, 0, 0, 0);
             __syncthreads();
-            for (uint32_t w = 0; w < (uint32_t)kPcWaves; ++w) {
-                const uint64_t sv = v_begin + (uint64_t)w * F * kPcBlockVecs;
-                const uint64_t b = sv + (uint64_t)seg * kPcBlockVecs, e = sv + (uint64_t)seg_end * kPcBlockVecs;
-                pc_slow_range(hist, bp, text, n, n_full, b, e);
-            }
+            pc_slow_range(hist, bp, text, n, n_full, v_begin + (uint64_t)seg * kIterVecs, v_begin + (uint64_t)seg_end * kIterVecs);
             resid = pc_check(hist, 0, red).sum;
             seg_iters = seg_iters >= 32 ? seg_iters / 4 : 8;
         }
@@ -776,6 +821,7 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t
         }
     }
     __syncthreads();
+    PC_STAMP();
     pc_flush(hist, bp);
     // ragged tail: pairs starting at byte 16*n_full - 1 .. n-2
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
@@ -784,6 +830,12 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t
         if (n_full * 16 == n) i = n;         // no tail at all
         for (; i + 1 < n; ++i) atomicAdd(&bp[((uint32_t)text[i] << 8) | text[i + 1]], 1u);
     }
+#ifdef MBPE_PC_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    PC_STAMP();
+    if (threadIdx.x == 0) for (; n_stamp < 16; ++n_stamp) stamps[n_stamp] = 0;
+#endif
 }
 
 // ---- widen: byte corpus -> 16-bit slot stream ------------------------------
@@ -4710,7 +4762,10 @@ void launch_fill_u16(hipStream_t s, uint16_t *p, uint64_t n, uint16_t v) {
     hipLaunchKernelGGL(k_fill_u16, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, s, p, n, v);
 }
 
-size_t pair_count_scratch_bytes(int n_workgroups) { return (size_t)(n_workgroups < 1 ? 1 : n_workgroups) * kPcWords * 4; }
+size_t pair_count_scratch_bytes(int n_workgroups) {
+    const size_t wgs = (size_t)(n_workgroups < 1 ? 1 : n_workgroups);
+    return wgs * kPcWords * 4 + wgs * 16 * 8;          // snapshots + (diagnostic builds) 16 time stamps per workgroup
+}
 
 void launch_pair_count_u8(hipStream_t s, const uint8_t *text, uint64_t n, const uint8_t *endmask,
                           uint32_t *bp, int n_workgroups, uint32_t *scratch, hipEvent_t start, hipEvent_t stop) {

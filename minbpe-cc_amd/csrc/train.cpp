@@ -736,6 +736,24 @@ int mbpe_pair_count_u8(mbpe_ctx *c, uint32_t *table65536_out) {
         c->stats.ms_pair_count_kernel = sum / (float)reps;
     }
     c->stats.pair_count_launches += (uint32_t)reps;
+#ifdef MBPE_PC_STAMPS
+    {   // diagnostic build: the phases of the last launch, per workgroup (k_pair_count_u8_fast's stamps, 10 ns units)
+        std::vector<unsigned long long> st((size_t)c->n_cus * 16);
+        HIPCHK(hipMemcpy(st.data(), reinterpret_cast<const char *>(c->pc_scratch) + (size_t)c->n_cus * 32768 * 4, st.size() * 8,
+                         hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < c->n_cus; ++w) if (st[16 * w] && st[16 * w] < t0) t0 = st[16 * w];
+        for (int k = 0; k < 16; ++k) {
+            double lo = 1e30, hi = 0, sum = 0; int cnt = 0;
+            for (int w = 0; w < c->n_cus; ++w) {
+                if (!st[16 * w + k]) continue;
+                const double us = (double)(st[16 * w + k] - t0) * 0.01;
+                lo = std::min(lo, us); hi = std::max(hi, us); sum += us; ++cnt;
+            }
+            if (cnt) fprintf(stderr, "pc stamp %2d: min %8.2f avg %8.2f max %8.2f us (%d workgroups)\n", k, lo, sum / cnt, hi, cnt);
+        }
+    }
+#endif
     return MBPE_OK;
 }
 
