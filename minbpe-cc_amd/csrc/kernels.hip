@@ -48,10 +48,11 @@ __device__ __forceinline__ uint32_t wave_from_prev(uint32_t v, uint32_t edge) {
 __device__ __forceinline__ bool lane_of(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
 #define MBPE_GLOBAL_AS __attribute__((address_space(1)))
-// the stream's tile loads and the fused pass's tile stores as non-temporal accesses (A/B: does the Infinity Cache then
-// keep the count-delta block, which the atomics of a large batch hit at random?)
+// The stream's tile loads and the fused pass's tile stores are non-temporal accesses: a pass reads and writes gigabytes
+// once each, and what profits from the caches is the count-delta block its atomics hit at random.  Same box, whole
+// training of the benchmark workload: 76,800 -> 79,100 merges/s, fused pass 5.19 -> 5.01 ms on average (0: plain, A/B).
 #ifndef MBPE_NT_STREAM
-#define MBPE_NT_STREAM 0
+#define MBPE_NT_STREAM 1
 #endif
 // a wave-uniform address, pinned to scalar registers
 __device__ __forceinline__ uintptr_t uniform_ptr(uintptr_t p) {
@@ -1387,7 +1388,10 @@ __global__ __launch_bounds__(kHierThreads) void k_argmax_hier(PairTable t, const
 // reference's loop breaks (Tokenizer.h:586-588); mbpe_train_result cuts the merges there.
 constexpr uint32_t kFirstBitmapWords = 2048;          // 64 Ki bits
 struct FirstState {
-    unsigned long long pos_key;      // (slot position << 32) | key of the earliest tied pair; ~0: none yet
+    unsigned long long pos_key;      // (tile index << 32) | key of the earliest tied pair; ~0: none yet.  (A tile is walked by
+                                     //   one wave, which reports only the earliest hit inside it: the tile index orders the
+                                     //   reports, so the stream may be as long as the library allows -- 2^28 tiles -- where a
+                                     //   slot position in these 32 bits ended at 4 GiB)
     uint32_t n_tie;                  // pairs whose count is the maximum
     uint32_t pad;
     uint32_t bitmap[kFirstBitmapWords];
@@ -1473,7 +1477,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_first_pos(const uint16_t *__r
     for (uint32_t tile = rfl(blockIdx.x * waves_per_block + threadIdx.x / kWave); tile < n_tiles; tile += n_waves) {
         // tiles are visited in ascending order: nothing at or after this one can win any more
         const unsigned long long cur = __hip_atomic_load(&fs->pos_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((cur >> 32) < (unsigned long long)tile * kTile) break;
+        if ((cur >> 32) < (unsigned long long)tile) break;
         const uint4 q = reinterpret_cast<const uint4 *>(tok)[(uint64_t)tile * kWave + lane];
         uint32_t s[8];
         unpack8(q, s);
@@ -1511,8 +1515,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_first_pos(const uint16_t *__r
         if (hit) {
             const uint32_t w = (uint32_t)__builtin_ctzll(hit);           // lowest lane = earliest position
             const uint32_t pos = rlane(my_pos, w), key = rlane(my_key, w);
-            if (lane == 0)
-                atomicMin(&fs->pos_key, (((unsigned long long)tile * kTile + pos) << 32) | key);
+            (void)pos;
+            if (lane == 0) atomicMin(&fs->pos_key, ((unsigned long long)tile << 32) | key);
             break;                                        // every later tile of this wave lies behind it
         }
     }
@@ -4903,7 +4907,7 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap, bool byte_table) {
+                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap, bool byte_table, int attempts) {
     const uint32_t fake_id = (endbit == kEndBit ? 0x7FFFu : 0xFFFFu) - 1u;      // see tt_rename
     // stand-in ids of (t,t) members are the kTTMax ids below the hole / end-bit mask: only while no token has them
     const uint32_t tt_max = 256u + n_target <= fake_id + 1u - (uint32_t)kTTMax ? (uint32_t)kTTMax : 1u;
@@ -4911,7 +4915,9 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
     if (sel_cap > kSelCap) sel_cap = kSelCap;
     if (sel) {
         const int blocks = (n_cus > 0 ? n_cus : 256) * 4;
-        for (int attempt = 0; attempt < 3; ++attempt) {
+        // (attempts 1 and 2 only work after an overflowing or empty first gather; when they are needed and were not
+        //  enqueued the bound-walking kernel below selects -- slower, never wrong)
+        for (int attempt = 0; attempt < (attempts < 1 ? 1 : attempts > 3 ? 3 : attempts); ++attempt) {
             hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target, sel_cap, attempt);
             hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
                                fused_min, (uint32_t)n_ranks, attempt, fake_id, sel_cap, tt_max, byte_table ? 1u : 0u);

@@ -311,9 +311,10 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 // prefix), then k_select_batch (walks the argmax bounds one pair at a time) if that could not be used
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap, bool byte_table);
-// (three gather + pick attempts are enqueued: when the first gather overflows its list -- many equal
-//  counts -- the second lists the block bounds to find a threshold and the third gathers with it)
+                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap, bool byte_table, int attempts = 3);
+// (up to three gather + pick attempts are enqueued: when the first gather overflows its list -- many equal
+//  counts -- the second lists the block bounds to find a threshold and the third gathers with it.  `attempts` 1: only
+//  the first; the host enqueues the other two while selections have needed them lately)
 // small batch: count the deltas and mark the tiles (the rewrite follows validation)
 void launch_scan_batch(hipStream_t s, const uint16_t *tok0, const uint16_t *tok1, const TileSum *sums,
                        uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,

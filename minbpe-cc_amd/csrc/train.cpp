@@ -215,6 +215,8 @@ struct mbpe_ctx {
     int64_t opt_first = 0;          // 1: `first` tie-break (insertion order, PairCount.h:65-74) instead of lexical
     int64_t opt_pc_repeat = 1;      // mbpe_pair_count_u8 without an output table: launches per call (timing)
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
+    int sel_attempts = 3;           // gather + pick attempts enqueued per selection: 1 while the last group of sequences
+                                    //   neither retried nor fell back to the bound-walking kernel (4 empty launches less)
     uint32_t max_batch_eff = kBatchMax, adj_pitch = kBatchMax;   // (set by mbpe_train_begin: see begin_local)
     // multi-GPU: what the selection of the sequence in flight decided (k_done, k_limit, batch_n, commit_n of DevCtl),
     // read back while its stream pass runs, so that exactly the cells the batch can touch are exchanged
@@ -784,6 +786,7 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     c->n_valid = 0;
     c->exhausted = false;
     c->first_legacy = false;
+    c->sel_attempts = 3;             // (the first selection of a training primes its threshold through attempts 1 and 2)
     c->merges_per_seq = 0;
     c->first_b = c->first_s = 0;
 
@@ -990,7 +993,7 @@ static int seq_stage_a(mbpe_ctx *c, int ev_slot) {       // up to the delta exch
     const RankEdge *le = multi ? c->d_left : nullptr, *re = multi ? c->d_right : nullptr;
     launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best,
                         c->n_target, std::min<uint32_t>((uint32_t)c->opt_max_batch, c->max_batch_eff), (uint32_t)c->opt_fused_min, c->n_cus,
-                        std::max(1, c->n_ranks), endbit, (uint32_t)c->opt_sel_cap, c->opt_byte_table);
+                        std::max(1, c->n_ranks), endbit, (uint32_t)c->opt_sel_cap, c->opt_byte_table, c->sel_attempts);
     if (c->opt_first)
         launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best, c->first_state, c->tok[0], c->tok[1], c->sums, c->n_tiles,
                               endbit, c->n_cus, 1);
@@ -1097,8 +1100,8 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
         c->wide = true;
         vocab_size = c->opt_wide_from >= 0 ? (uint32_t)std::min<int64_t>(256 + c->opt_wide_from, vmax) : vmax;
     }
-    if (c->opt_first && (is_multi(c) || c->n_bytes + (c->barrier ? c->n_barriers : 0) >= 0xFFFFFE00ull)) {
-        mbpe_host::set_last_error("conflict_resolution first: one GPU and a corpus below 4 GiB only");
+    if (c->opt_first && is_multi(c)) {
+        mbpe_host::set_last_error("conflict_resolution first: one GPU only");
         return MBPE_ERR_STATE;
     }
     HIPCHK(hipSetDevice(c->device));
@@ -1148,6 +1151,7 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
         // (for THIS group: the "batch" / "max_batch" options may have changed since the bound was last computed)
         update_hot_possible(c, c->last_top, (uint64_t)group * kBatchMax);
         const uint32_t batches_before = c->h_ctl.n_batches, singles_before = c->h_ctl.cut_single;
+        const uint32_t retry_before = c->h_ctl.n_sel_retry + c->h_ctl.n_sel_fallback;
         unsigned long long live_prev = c->h_ctl.n_live;      // (exact: the host synchronised before this group)
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         uint32_t launched = 0;
@@ -1208,6 +1212,8 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
             }
             c->stats.merge_launches += c->h_ctl.n_batches - batches_before;   // sequences that did work
         }
+        // (the selection's second and third attempts: only enqueued while the last group needed one, or the fallback)
+        c->sel_attempts = (c->h_ctl.n_sel_retry + c->h_ctl.n_sel_fallback != retry_before || c->comm_external) ? 3 : 1;
         const uint32_t before = c->k;
         c->k = c->h_ctl.k_done;
         if (c->k) {             // the count of the latest merge bounds every later one

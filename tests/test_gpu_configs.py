@@ -137,6 +137,67 @@ def test_config4_merge_order_at_checkpoints_1gib(dev):
         assert len(m) == total and C.counts_nonincreasing(c)
 
 
+def test_config4_order_inside_large_batches_4gib(dev):
+    """BASELINE config 4 at its full size with default options: 48 checkpoints at RANDOM merge counts, three quarters of
+    them inside merges 300..17,000 -- the phase whose batches hold 1,000-4,096 pairs (the 128 x 128 pairs of two halves
+    of the byte alphabet) -- so that train_steps(n) cuts those batches at arbitrary members.  At every checkpoint the
+    table equals a recount of the stream, cell by cell, and the merge committed next is the recount's argmax under
+    (count desc, first asc, second asc), PairCount.h:194-207, :262-269; a second, uninterrupted training gives the same
+    merges, so the order inside the batches that were NOT cut is the one the cut ones proved."""
+    from bench import splitmix64_device
+    n = 4 << 30
+    keep, corpus = splitmix64_device(42, n, dev)
+    torch.cuda.synchronize()
+    total = 32000 - 256
+    rng = np.random.default_rng(4)
+    ats = sorted(set([int(x) for x in rng.integers(300, 17000, size=36)] + [int(x) for x in rng.integers(17000, total - 1, size=12)]))
+    with mbpe.Trainer(0) as tr:
+        tr.load_corpus_device(corpus.data_ptr(), n, keep=keep)
+        tr.train_begin(32000)
+        big = 0
+        for at in ats:
+            have = len(tr.train_result()[0])
+            if at > have:
+                before = tr.stats()["n_batches"]
+                assert tr.train_steps(at - have) == at - have
+                # (merges per pass since the last checkpoint: thousands in the phase this test is about)
+                if (at - have) / max(tr.stats()["n_batches"] - before, 1) >= 1000:
+                    big += 1
+            r = C.argmax_at_checkpoint(tr, torch, dev)
+            assert r["ok"] and r["merge"] == at, r
+        assert big >= 8, big
+        tr.train_steps(total)
+        m1, c1 = tr.train_result()
+        assert len(m1) == total and C.counts_nonincreasing(c1)
+        tr.train_begin(32000)
+        assert tr.train_steps(total) == total
+        m2, c2 = tr.train_result()
+        assert np.array_equal(m1, m2) and np.array_equal(c1, c2)
+
+
+def test_config4_first_1500_merges_against_oracle_16mib(dev):
+    """16 MiB of the benchmark bytes, default options, the first 1,500 merges against the oracle (every pair and count),
+    then stream and pair table: batches of hundreds of pairs, pass-overs, the byte-table lookup."""
+    n = 16 << 20
+    data = O.splitmix64_bytes(42, n)
+    k = 1500
+    with mbpe.Trainer(0) as tr:
+        tr.load_corpus(data)
+        tr.train_begin(32000)
+        assert tr.train_steps(k) == k
+        m, c = tr.train_result()
+        st = tr.stats()
+        assert st["n_batches"] < k // 20
+        ost = O.State(data)
+        for i in range(k):
+            top = ost.top()
+            assert (int(m[i][0]), int(m[i][1]), int(c[i])) == top, i
+            ost.merge(top[0], top[1], 256 + i)
+        assert np.array_equal(tr.stream()[0], ost.stream()[0])
+        assert {kk: v for kk, v in tr.pairs_dict().items() if v} == {kk: v for kk, v in ost.table_dict().items() if v}
+        ost.close()
+
+
 @pytest.mark.parametrize("chunked", [False, True])
 def test_text_merge_order_at_checkpoints_71mb(dev, chunked):
     """The same proof on text (shakespeare.txt x 64, 71 MB; whole and under the GPT-4 split pattern, chunk ends as
