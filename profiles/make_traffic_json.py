@@ -10,8 +10,9 @@ d = sys.argv[1]
 tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 out = {
     "workload": {"config": "synthetic", "corpus_bytes": 4 << 30, "vocab_size": 32000, "n_gpus": 1,
-                 "command": "bench.py --steps 20 --warmup 5 --no-full-run --no-cpu-baseline (sequences 0..25: 4.29e9 "
-                            "slots, live tokens 4.29e9 -> 3.8e9); averages over the working dispatches of each kernel"},
+                 "command": os.environ.get("MBPE_TRAFFIC_COMMAND",
+                                           "bench.py --steps 20 --warmup 5 --no-full-run --no-cpu-baseline (sequences 0..25: 4.29e9 "
+                                           "slots, live tokens 4.29e9 -> 3.8e9)") + "; averages over the working dispatches of each kernel"},
     "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs; bytes = KB x 1024, FETCH_SIZE doubled "
               "(gfx950 wide-read correction, /opt/skills/guides/MI355X_MICROARCH.md, HBM)",
 }

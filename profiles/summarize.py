@@ -4,6 +4,7 @@ small per-kernel summaries committed under profiles/.
 
 usage: summarize.py stats <kernel_stats.csv> | trace <kernel_trace.csv> | pmc <counter_collection.csv>
                     | sq <counter_collection.csv>   (any other counters: raw per-dispatch averages)
+                    | pc <kernel_trace.csv>         (the pair-count scan's launches of the benchmark size only)
 PMC note (guide: /opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE and
 WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced read, so the corrected read traffic is 2 x FETCH_SIZE x 1024.
@@ -41,6 +42,27 @@ def main():
             w = [x for x in v if x >= 20.0]
             print("%s,%d,%.3f,%d,%.3f,%.2f,%.2f" % (k, len(v), sum(v) / 1e3, len(w), sum(w) / 1e3,
                                                   sum(w) / max(len(w), 1), max(v)))
+    elif mode == "pc":
+        # The pair-count scan alone.  A bench.py process launches it on the benchmark corpus (inside every training and
+        # in the timed groups at the end) AND on small inputs (published_workload: 1.1 MB, ~40 us): an average over
+        # all calls -- what rocprofv3's kernel_stats gives -- is diluted by the small ones (round 3's "0.525").  Only
+        # launches of at least half the longest one count here.
+        v = []
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            if k and k.startswith("k_pair_count"):
+                v.append((float(r["Start_Timestamp"]), (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3))
+        v.sort()
+        d = [x for _, x in v]
+        full = [x for x in d if x >= 0.5 * max(d)]
+        last30 = full[-30:]
+        print("k_pair_count launches,%d" % len(d))
+        print("launches of the benchmark size (>= half the longest),%d" % len(full))
+        print("their mean_us,%.2f" % (sum(full) / len(full)))
+        print("their min_us,%.2f" % min(full))
+        print("their max_us,%.2f" % max(full))
+        print("mean_us of the last 30 of them (bench.py's timed groups),%.2f" % (sum(last30) / len(last30)))
+        print("of the 8 TB/s peak at 2^32 bytes (last 30),%.4f" % (4294967296.0 / (sum(last30) / len(last30) * 1e-6) / 8e12))
     elif mode == "trace20":
         # the driver's timed region: the k_fused_batch working dispatches number 6..25 (5 warm-up sequences,
         # 20 timed ones; the first passes of a run are fused from the second sequence on) and everything between

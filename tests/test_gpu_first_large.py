@@ -23,7 +23,7 @@ def test_first_mode_text_x1000_equals_one_copy():
     one = np.frombuffer(read_data("shakespeare.txt"), dtype=np.uint8)
     copies = 1000
     off1 = np.asarray(mbpe.presplit(O.GPT4_SPLIT_PATTERN, one), dtype=np.uint64)
-    vocab = 256 + 48
+    vocab = 256 + 200            # (lexical and first order part ways at merge 147 on this text)
     want_m, want_c = O.train(one, vocab, off1, mode=O.FIRST)
     data = np.tile(one, copies)
     base = (np.arange(copies, dtype=np.uint64) * np.uint64(len(one)))[:, None]
