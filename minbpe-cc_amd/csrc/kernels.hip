@@ -4846,18 +4846,23 @@ void launch_first_tiebreak(hipStream_t s, PairTable t, const DevCtl *ctl, unsign
     hipLaunchKernelGGL(k_first_pick, dim3(1), dim3(256), 0, s, best, fs, ctl, seq);
 }
 
+// runs of t before every tile, for the (t,t) pair of a single merge or the (t,t) member(s) of a batch
+void launch_run_lengths(hipStream_t s, const TileSum *sin, uint32_t n_tiles, const unsigned long long *best, const DevCtl *ctl,
+                        int seq, const BatchState *bs, unsigned long long *run_part, const RankEdge *left_edge, uint32_t *run_in) {
+    if (!n_tiles) return;
+    const uint32_t n_chunks = (n_tiles + kRunChunk - 1) / kRunChunk;
+    hipLaunchKernelGGL(k_run_partial, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, bs, run_part);
+    hipLaunchKernelGGL(k_run_final, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, bs, run_part,
+                       left_edge, run_in);
+}
+
 void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileSum *sin, TileSum *sout, uint32_t n_tiles,
                   uint32_t *chg, const unsigned long long *best, uint32_t new_id, uint32_t endbit, uint32_t *LR,
                   DevCtl *ctl, uint32_t *m_adj, const RankEdge *left_edge, const RankEdge *right_edge, int n_cus,
-                  int seq, unsigned long long *run_part, uint32_t *run_in, const BatchState *bs, int hot_possible) {
+                  int seq, unsigned long long *run_part, uint32_t *run_in, const BatchState *bs, int hot_possible, int only) {
     if (!n_tiles) return;
-    {   // runs of t before every tile, for a (t,t) pair (the kernels return at once for any other pair)
-        const uint32_t n_chunks = (n_tiles + kRunChunk - 1) / kRunChunk;
-        hipLaunchKernelGGL(k_run_partial, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, bs,
-                           run_part);
-        hipLaunchKernelGGL(k_run_final, dim3(n_chunks), dim3(kRunThreads), 0, s, sin, n_tiles, best, ctl, seq, bs,
-                           run_part, left_edge, run_in);
-    }
+    // runs of t before every tile, for a (t,t) pair (the kernels return at once for any other pair)
+    if (only < 0 || (only & 1)) launch_run_lengths(s, sin, n_tiles, best, ctl, seq, bs, run_part, left_edge, run_in);
     static const int occ[3] = {resident_blocks(k_merge<0, false, 0>), resident_blocks(k_merge<1, false, 0>),
                                resident_blocks(k_merge<2, false, 0>)};
     const dim3 grid(tile_grid(n_tiles, n_cus, occ[slot_mode(endbit)])), block(kMergeThreads);
@@ -4874,11 +4879,13 @@ void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileS
         return;
     }
 #endif
-    // (both instantiations: each returns at once unless the pair's frequency is its case)
+    // (both instantiations: each returns at once unless the pair's frequency is its case; only >= 0: exactly the one
+    //  the host knows this merge takes -- bit 1: the frequent-pair instantiation)
     MBPE_BY_MODE(endbit, {
-        hipLaunchKernelGGL((k_merge<M, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
-                           m_adj, left_edge, right_edge, seq, run_in, hot_possible);
-        if (hot_possible)
+        if (only < 0 || !(only & 2))
+            hipLaunchKernelGGL((k_merge<M, false, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR, ctl,
+                               m_adj, left_edge, right_edge, seq, run_in, hot_possible);
+        if (only < 0 ? hot_possible != 0 : (only & 2) != 0)
             hipLaunchKernelGGL((k_merge<M, true, 0>), grid, block, 0, s, tok, tok_other, sin, sout, n_tiles, chg, best, new_id, LR,
                                ctl, m_adj, left_edge, right_edge, seq, run_in, hot_possible);
     });
@@ -4930,7 +4937,7 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
                         uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible) {
+                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible, int only) {
     if (!n_tiles) return;
     static const int occ[3] = {resident_blocks(k_fused_batch<0, false, false, 0>, kLutThreads),
                                resident_blocks(k_fused_batch<1, false, false, 0>, kLutThreads),
@@ -4954,23 +4961,26 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
 #undef MBPE_FUSED_DIAG_CASE
 #endif
     MBPE_BY_MODE(endbit, {
-        hipLaunchKernelGGL((k_fused_batch<M, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
-        hipLaunchKernelGGL((k_fused_batch<M, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                           LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
-        if (hot_possible) {
+        // (only >= 0: exactly the instantiation the host knows this batch takes -- bit 0: (t,t) member, bit 1: frequent pair)
+        if (only < 0 || only == 0)
+            hipLaunchKernelGGL((k_fused_batch<M, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
+        if (only < 0 || only == 1)
+            hipLaunchKernelGGL((k_fused_batch<M, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
+        if (only < 0 ? hot_possible != 0 : only == 2)
             hipLaunchKernelGGL((k_fused_batch<M, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                                LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
+        if (only < 0 ? hot_possible != 0 : only == 3)
             hipLaunchKernelGGL((k_fused_batch<M, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
                                LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
-        }
     });
 }
 
 void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1, const TileSum *sums, uint32_t n_tiles,
                        uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
                        const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                       int n_cus, const uint32_t *run_in, int hot_possible) {
+                       int n_cus, const uint32_t *run_in, int hot_possible, int only) {
     if (!n_tiles) return;
     static const int occ[3] = {resident_blocks(k_scan_batch<0, false, false, 0>, kLutThreads),
                                resident_blocks(k_scan_batch<1, false, false, 0>, kLutThreads),
@@ -4991,16 +5001,18 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
 #undef MBPE_SCAN_DIAG_CASE
 #endif
     MBPE_BY_MODE(endbit, {
-        hipLaunchKernelGGL((k_scan_batch<M, false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj,
-                           LR, ctl, left_edge, right_edge, run_in, hot_possible);
-        hipLaunchKernelGGL((k_scan_batch<M, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj,
-                           LR, ctl, left_edge, right_edge, run_in, hot_possible);
-        if (hot_possible) {
+        if (only < 0 || only == 0)
+            hipLaunchKernelGGL((k_scan_batch<M, false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj,
+                               LR, ctl, left_edge, right_edge, run_in, hot_possible);
+        if (only < 0 || only == 1)
+            hipLaunchKernelGGL((k_scan_batch<M, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj,
+                               LR, ctl, left_edge, right_edge, run_in, hot_possible);
+        if (only < 0 ? hot_possible != 0 : only == 2)
             hipLaunchKernelGGL((k_scan_batch<M, true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m,
                                hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible);
+        if (only < 0 ? hot_possible != 0 : only == 3)
             hipLaunchKernelGGL((k_scan_batch<M, true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m,
                                hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible);
-        }
     });
 }
 
@@ -5033,7 +5045,7 @@ void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 void launch_rewrite_marked(hipStream_t s, uint16_t *tok, uint16_t *tok1, const TileSum *sums, TileSum *side, uint32_t n_tiles,
                            uint32_t *chg, uint32_t *list, const BatchState *bs, DevCtl *ctl,
                            const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus,
-                           const uint32_t *run_in) {
+                           const uint32_t *run_in, int only) {
     if (!n_tiles) return;
     const uint32_t n_words = (n_tiles + 31u) / 32u;
     hipLaunchKernelGGL(k_list_marked, dim3((n_words + 255) / 256), dim3(256), 0, s, chg, n_words, list, ctl, n_tiles);
@@ -5042,11 +5054,43 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok, uint16_t *tok1, const T
                                resident_blocks(k_rewrite_marked<2, false>, kLutThreads)};
     const dim3 grid(tile_grid(n_tiles, n_cus, occ[slot_mode(endbit)], kLutThreads)), block(kLutThreads);
     MBPE_BY_MODE(endbit, {
+        // (only >= 0, bit 0: the batch has a (t,t) member.  Validation may keep a prefix that ends before it: then the
+        //  other instantiation is the one that works, so both are enqueued for such a batch)
         hipLaunchKernelGGL((k_rewrite_marked<M, false>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
                            left_edge, right_edge, run_in);
-        hipLaunchKernelGGL((k_rewrite_marked<M, true>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
-                           left_edge, right_edge, run_in);
+        if (only < 0 || (only & 1))
+            hipLaunchKernelGGL((k_rewrite_marked<M, true>), grid, block, 0, s, tok, tok1, sums, side, n_tiles, chg, list, bs, ctl,
+                               left_edge, right_edge, run_in);
     });
+}
+
+// What the selection of the sequence under way decided, for a host that enqueues only the kernels this sequence needs
+// (small corpora, train.cpp: lockstep): merges done, pairs in the batch, fused pass or not, a (t,t) pair in it, and whether
+// the pass is the frequent-pair instantiation's (dc_wanted, exactly as the stream kernels decide it).
+__global__ void k_seq_info(const DevCtl *ctl, const BatchState *bs, const unsigned long long *best, uint32_t *out) {
+    if (blockIdx.x || threadIdx.x) return;
+    const uint32_t n = ctl->batch_n;
+    unsigned long long top = 0;
+    uint32_t tt = 0;
+    if (n >= 2) {
+        top = bs->packed[0] >> 32;
+        tt = bs->tt_index != kNoTT ? 1u : 0u;
+    } else if (n == 1) {
+        const unsigned long long b = best[ctl->k_done];
+        const uint32_t key = ~(uint32_t)b;
+        top = b >> 32;
+        tt = (top != 0 && (key >> 16) == (key & 0xFFFFu)) ? 1u : 0u;
+    }
+    out[0] = ctl->k_done;
+    out[1] = n;
+    out[2] = ctl->fused;
+    out[3] = tt;
+    out[4] = dc_wanted(top, ctl->n_live * ctl->n_ranks) ? 1u : 0u;
+    out[5] = ctl->k_limit;
+}
+
+void launch_seq_info(hipStream_t s, const DevCtl *ctl, const BatchState *bs, const unsigned long long *best, uint32_t *out) {
+    hipLaunchKernelGGL(k_seq_info, dim3(1), dim3(64), 0, s, ctl, bs, best, out);
 }
 
 void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag, const BatchState *bs) {

@@ -292,7 +292,12 @@ void launch_merge(hipStream_t s, uint16_t *tok, uint16_t *tok_other, const TileS
                   unsigned long long *run_part /* tile_scan_scratch(n_tiles) entries */,
                   uint32_t *run_in /* n_tiles entries: run of t before every tile, for (t,t) pairs */,
                   const BatchState *bs /* seq != 0: a batch may hold a (t,t) member */,
-                  int hot_possible = 1 /* 0: the frequent-pair (delta cache) instantiations cannot be needed: not launched */);
+                  int hot_possible = 1 /* 0: the frequent-pair (delta cache) instantiations cannot be needed: not launched */,
+                  int only = -1 /* >= 0: launch exactly one instantiation -- bit 0: the pair is a (t,t) pair (run kernels),
+                                   bit 1: the frequent-pair one (launch_seq_info told the host) */);
+// the run kernels launch_merge starts with, alone (a host that enqueues a batch's pass by itself: train.cpp, lockstep)
+void launch_run_lengths(hipStream_t s, const TileSum *sums, uint32_t n_tiles, const unsigned long long *best, const DevCtl *ctl,
+                        int seq, const BatchState *bs, unsigned long long *run_part, const RankEdge *left_edge, uint32_t *run_in);
 // seq != 0: the kernel runs inside a batch sequence: it reads the merge index
 // from ctl->k_done and returns at once unless the selected batch has one pair;
 // tok / tok_other are then token buffers 0 / 1 and ctl->cur picks the live one
@@ -319,19 +324,23 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 void launch_scan_batch(hipStream_t s, const uint16_t *tok0, const uint16_t *tok1, const TileSum *sums,
                        uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                        uint32_t *LR, const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge,
-                       uint32_t endbit, int n_cus, const uint32_t *run_in, int hot_possible = 1);
+                       uint32_t endbit, int n_cus, const uint32_t *run_in, int hot_possible = 1, int only = -1);
 // large batch (ctl->fused): count the deltas and write the merged stream to the other buffer
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
                         uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible = 1);
+                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible = 1, int only = -1);
 // k_delta_max + k_validate + k_apply_batch
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                          uint32_t *LR, uint32_t id_upper, uint32_t n_hint);
 void launch_rewrite_marked(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side, uint32_t n_tiles,
                            uint32_t *chg, uint32_t *list /* [n_tiles] scratch */, const BatchState *bs, DevCtl *ctl,
                            const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit, int n_cus,
-                           const uint32_t *run_in /* as for launch_merge: used when the batch has a (t,t) member */);
+                           const uint32_t *run_in /* as for launch_merge: used when the batch has a (t,t) member */,
+                           int only = -1);
+// what the selection decided, for a host that enqueues only the kernels a sequence needs: out[0] merges done, [1] pairs
+// in the batch, [2] fused pass, [3] a (t,t) pair among them, [4] frequent-pair instantiation, [5] merge limit
+void launch_seq_info(hipStream_t s, const DevCtl *ctl, const BatchState *bs, const unsigned long long *best, uint32_t *out);
 // fused_flag (optional, 4 words): [0] = 1 when this sequence ran the fused pass, [1..2] = live tokens of the shard after
 // the sequence, [3] = merges it committed
 void launch_seq_finish(hipStream_t s, DevCtl *ctl, uint32_t *fused_flag, const BatchState *bs);

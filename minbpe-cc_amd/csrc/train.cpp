@@ -220,7 +220,10 @@ struct mbpe_ctx {
     uint32_t max_batch_eff = kBatchMax, adj_pitch = kBatchMax;   // (set by mbpe_train_begin: see begin_local)
     // multi-GPU: what the selection of the sequence in flight decided (k_done, k_limit, batch_n, commit_n of DevCtl),
     // read back while its stream pass runs, so that exactly the cells the batch can touch are exchanged
-    uint32_t *h_seq = nullptr;      // pinned, 4 words
+    uint32_t *h_seq = nullptr;      // pinned, 16 words: [0..3] the multi-GPU copy, [8..13] launch_seq_info's
+    uint32_t *d_seq_info = nullptr; // 8 words of device memory for launch_seq_info
+    int64_t opt_lockstep = -1;      // small corpora: the host waits for every selection and enqueues only the kernels that
+                                    //   sequence needs (-1: when the stream is short enough, 0 never, 1 always)
     hipEvent_t ev_sel = nullptr;
     std::vector<hipEvent_t> kev;    // event pool for opt_time_kernels
     std::vector<hipEvent_t> kev_f;  // ... around the fused pass alone
@@ -516,6 +519,7 @@ void mbpe_destroy(mbpe_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
     if (c->h_seq) (void)hipHostFree(c->h_seq);
+    dfree(c->d_seq_info);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -547,6 +551,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "first_batches") c->opt_first_batches = value != 0;
     else if (n == "sel_cap") c->opt_sel_cap = std::min<int64_t>(std::max<int64_t>(64, value), kSelCap);
     else if (n == "byte_table") c->opt_byte_table = value != 0;
+    else if (n == "lockstep") c->opt_lockstep = value < 0 ? -1 : value != 0;
     else if (n == "wide_from") c->opt_wide_from = value < 0 ? -1 : value;      // (read by the next mbpe_train_begin)
     else if (n == "pc_repeat") c->opt_pc_repeat = std::min<int64_t>(std::max<int64_t>(1, value), 1000);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
@@ -987,6 +992,67 @@ static inline bool use_batches(const mbpe_ctx *c) {
     return c->opt_multi_merge != 0 && (!c->opt_first || (c->opt_first_batches && !c->first_legacy));
 }
 
+// Small corpora: a sequence is ~25 launches of which ~16 return at once (the device decides which stream kernel of which
+// instantiation works), and at 4-5 us per dispatch those are a third of a 0.16 ms sequence (BASELINE config 3).  There the
+// host waits for the selection's result -- one event wait per sequence, ~20 us -- and enqueues exactly the pass, the
+// tables / the single-pair apply and the rewrite this sequence needs.
+static constexpr uint64_t kLockstepSlots = 32ull << 20;
+static inline bool use_lockstep(const mbpe_ctx *c) {
+    if (is_multi(c) || c->opt_first) return false;
+    if (c->opt_lockstep >= 0) return c->opt_lockstep != 0;
+    return c->n_slots <= kLockstepSlots;
+}
+
+static int seq_lockstep(mbpe_ctx *c, int ev_slot, bool *nothing_left) {
+    const uint32_t endbit = endbit_of(c);
+    *nothing_left = false;
+    launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best,
+                        c->n_target, std::min<uint32_t>((uint32_t)c->opt_max_batch, c->max_batch_eff), (uint32_t)c->opt_fused_min, c->n_cus,
+                        1, endbit, (uint32_t)c->opt_sel_cap, c->opt_byte_table, c->sel_attempts);
+    if (!c->d_seq_info) HIPCHK(hipMalloc(&c->d_seq_info, 32));
+    launch_seq_info(c->stream, c->ctl, c->bs, c->best, c->d_seq_info);
+    HIPCHK(hipMemcpyAsync(c->h_seq + 8, c->d_seq_info, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->ev_sel, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev_sel));
+    const uint32_t batch_n = c->h_seq[9], fused = c->h_seq[10], tt = c->h_seq[11], hot = c->h_seq[12];
+    if (ev_slot >= 0) { (void)hipEventRecord(c->kev[2 * ev_slot], c->stream); (void)hipEventRecord(c->kev_f[2 * ev_slot], c->stream); }
+    if (batch_n == 0) {                        // the merge limit is reached (or the table is empty): nothing to enqueue
+        if (ev_slot >= 0) { (void)hipEventRecord(c->kev_f[2 * ev_slot + 1], c->stream); (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream); }
+        *nothing_left = true;
+        return MBPE_OK;
+    }
+    const int only = (int)((tt ? 1u : 0u) | (hot ? 2u : 0u));
+    if (batch_n == 1) {
+        launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
+                     &c->ctl->m, nullptr, nullptr, c->n_cus, 1, c->offsets + c->n_tiles, c->run_in, c->bs, (int)hot, only);
+    } else {
+        // (a batch with a (t,t) member: the runs of its token before every tile, which launch_merge computes in the
+        //  ordinary enqueue-everything flow)
+        if (tt) launch_run_lengths(c->stream, c->sums, c->n_tiles, c->best, c->ctl, 1, c->bs, c->offsets + c->n_tiles, nullptr, c->run_in);
+    }
+    if (batch_n == 1) {
+    } else if (fused) {
+        launch_fused_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->bs, c->hdr_adj, c->LR,
+                           c->ctl, nullptr, nullptr, endbit, c->n_cus, c->hdr_m, c->run_in, (int)hot, only);
+    } else {
+        launch_scan_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
+                          c->ctl, nullptr, nullptr, endbit, c->n_cus, c->run_in, (int)hot, only);
+    }
+    if (ev_slot >= 0) { (void)hipEventRecord(c->kev_f[2 * ev_slot + 1], c->stream); (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream); }
+    c->k_upper = std::min<uint32_t>(c->n_target, c->h_seq[8] + batch_n);
+    const uint32_t id_upper = 256 + c->k_upper;
+    if (batch_n == 1) {
+        launch_apply(c->stream, c->tab, c->ctl, c->best, id_upper, c->LR, nullptr, c->sums, c->side, c->chg, c->n_tiles, 1);
+    } else {
+        launch_batch_tables(c->stream, c->tab, c->ctl, c->bs, c->hdr_m, c->hdr_adj, c->LR, id_upper, batch_n);
+        launch_rewrite_marked(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->tile_list, c->bs, c->ctl,
+                              nullptr, nullptr, endbit, c->n_cus, c->run_in, (int)(tt ? 1u : 0u));
+        launch_patch_sums(c->stream, c->best, c->sums, c->side, c->chg, c->n_tiles, c->ctl, 1);
+    }
+    launch_seq_finish(c->stream, c->ctl, c->seq_slot >= 0 ? c->seq_flags + 4 * c->seq_slot : nullptr, c->bs);
+    return MBPE_OK;
+}
+
 static int seq_stage_a(mbpe_ctx *c, int ev_slot) {       // up to the delta exchange
     const uint32_t endbit = endbit_of(c);
     const bool multi = is_multi(c);
@@ -1158,8 +1224,17 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
         // (sequences past the target do nothing on the device -- ctl->k_limit -- but cost their launches: enqueue
         //  as many as the last group's merges per sequence say are needed; before that is known, as many as are
         //  needed if every one merged max_batch pairs)
-        for (uint32_t g = 0; g < group && (c->merges_per_seq > 0 ? c->k + g * c->merges_per_seq < target : c->k_upper < target);
+        const bool lockstep = use_lockstep(c);
+        for (uint32_t g = 0; g < group && (lockstep || (c->merges_per_seq > 0 ? c->k + g * c->merges_per_seq < target : c->k_upper < target));
              ++g, ++launched) {
+            if (lockstep) {
+                bool nothing_left = false;
+                c->seq_slot = c->opt_time_kernels ? (int)g : -1;
+                const int rc = seq_lockstep(c, c->opt_time_kernels ? (int)g : -1, &nothing_left);
+                if (rc != MBPE_OK) return rc;
+                if (nothing_left) { ++launched; break; }
+                continue;
+            }
             {
                 const int rc = seq_stage_a(c, c->opt_time_kernels ? (int)g : -1);
                 if (rc != MBPE_OK) return rc;

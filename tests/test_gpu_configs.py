@@ -160,12 +160,13 @@ def test_config4_order_inside_large_batches_4gib(dev):
             if at > have:
                 before = tr.stats()["n_batches"]
                 assert tr.train_steps(at - have) == at - have
-                # (merges per pass since the last checkpoint: thousands in the phase this test is about)
-                if (at - have) / max(tr.stats()["n_batches"] - before, 1) >= 1000:
+                # (ONE pass of hundreds of merges up to the checkpoint: a batch that would have gone on -- the natural
+                #  batches of this phase hold 1,000-4,096 pairs -- cut at an arbitrary member by the merge limit)
+                if tr.stats()["n_batches"] - before == 1 and at - have >= 100:
                     big += 1
             r = C.argmax_at_checkpoint(tr, torch, dev)
             assert r["ok"] and r["merge"] == at, r
-        assert big >= 8, big
+        assert big >= 12, big
         tr.train_steps(total)
         m1, c1 = tr.train_result()
         assert len(m1) == total and C.counts_nonincreasing(c1)

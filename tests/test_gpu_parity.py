@@ -95,11 +95,16 @@ def test_train_golden_model_bytes(tr, name):
     data = _input(meta["input"])
     enc = meta["encoder"]
     off = None if enc == "basic" else mbpe.presplit(O.PATTERNS[enc], data)
-    merges, counts, stats = tr.train_lexical(data, meta["vocab"], off)
-    assert O.model_bytes(O.PATTERNS[enc], merges) == read_golden(name + ".model")
-    assert int(counts[0]) == meta["first_count"] and int(counts[-1]) == meta["last_count"]
-    # (a merge of (t,t) removes fewer tokens than its overlapping-window count)
-    assert stats["n_live"] == meta["final_len"] >= len(data) - int(counts.sum())
+    for lockstep in (0, 1):        # whole groups of sequences with every kernel variant / one sequence at a time, its kernels only
+        tr.set_option("lockstep", lockstep)
+        try:
+            merges, counts, stats = tr.train_lexical(data, meta["vocab"], off)
+        finally:
+            tr.set_option("lockstep", -1)
+        assert O.model_bytes(O.PATTERNS[enc], merges) == read_golden(name + ".model"), lockstep
+        assert int(counts[0]) == meta["first_count"] and int(counts[-1]) == meta["last_count"]
+        # (a merge of (t,t) removes fewer tokens than its overlapping-window count)
+        assert stats["n_live"] == meta["final_len"] >= len(data) - int(counts.sum())
 
 
 FIRST_GOLDENS = sorted(k for k, v in INDEX.items() if v["mode"] == "first")
@@ -256,7 +261,7 @@ def test_train_tiny_inputs(tr, data, vocab):
 
 DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 4096, "fused_min": 24, "hier_argmax": -1,
             "dense_table": -1, "threshold_select": 1, "sel_cap": 8192, "chunk_barrier": -1, "first_batches": 0, "byte_table": 1,
-            "wide_from": -1}
+            "wide_from": -1, "lockstep": -1}
 
 
 def _defaults(tr):
@@ -267,6 +272,9 @@ def _defaults(tr):
 def _step_parity(tr, data, off, vocab, stride=1, **opts):
     """After every `stride` merges (1 = every step; larger values let several independent
     merges share one stream pass): chosen pairs, counts, live stream, chunk ends, pair table."""
+    # (small corpora run in lockstep by default -- the host waits for every selection and enqueues only that sequence's
+    #  kernels; large ones enqueue whole groups with every kernel variant: the cases alternate between the two)
+    opts.setdefault("lockstep", (len(data) + vocab) & 1)
     for k, v in opts.items():
         tr.set_option(k, v)
     try:
