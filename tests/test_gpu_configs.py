@@ -188,7 +188,7 @@ def test_config4_first_1500_merges_against_oracle_16mib(dev):
         assert tr.train_steps(k) == k
         m, c = tr.train_result()
         st = tr.stats()
-        assert st["n_batches"] < k // 20
+        assert st["n_batches"] < k // 10
         ost = O.State(data)
         for i in range(k):
             top = ost.top()
