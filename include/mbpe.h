@@ -201,7 +201,9 @@ MBPE_API int mbpe_train_lexical(mbpe_ctx *ctx, const uint8_t *text, uint64_t n_b
  * before every merge wins (PairCountInsertOrder, PairCount.h:65-74, :141-152; recount
  * Tokenizer.h:581-585), i.e. the one whose first occurrence in the corpus comes first.  The
  * device keeps the exact counts incrementally and settles ties with one pass over the stream
- * that finds the earliest position of a tied pair; one merge per pass, one GPU.
+ * that finds the earliest position of a tied pair; one merge per pass.  On a sharded stream (several ranks) every rank
+ * finds the earliest tied pair of its shard and one more small exchange per merge -- the ranks' hits, the lowest rank
+ * that has one wins: shards follow each other in rank order -- makes the choice global.
  * With FIRST the loop ends when no pair is left (Tokenizer.h:586-588): n_merges_out may then be
  * smaller than vocab_size - 256.  Step-level use: mbpe_set_option("conflict_resolution", 0)
  * before mbpe_train_begin. */

@@ -1457,7 +1457,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_first_pos(const uint16_t *__r
                                                              const TileSum *__restrict__ sin, uint32_t n_tiles,
                                                              PairTable t,
                                                              const unsigned long long *__restrict__ best_ptr,
-                                                             FirstState *fs, const DevCtl *ctl, int seq) {
+                                                             FirstState *fs, const DevCtl *ctl, int seq,
+                                                             const RankEdge *__restrict__ re) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     __shared__ uint32_t bm[kFirstBitmapWords];
@@ -1489,10 +1490,13 @@ __global__ __launch_bounds__(kMergeThreads) void k_first_pos(const uint16_t *__r
         if (!m_live) continue;
         // first live token after this tile (only the last live lane needs it)
         uint32_t after = kHole;
+        bool found_after = false;
         for (uint32_t j = tile + 1; j < n_tiles; ++j) {
             const TileSum ns = sin[j];
-            if (ns.n_live) { after = ns.head0; break; }
+            if (ns.n_live) { after = ns.head0; found_after = true; break; }
         }
+        // (a sharded stream goes on in the next rank's shard: the pair of this shard's last token belongs to this rank)
+        if (!found_after && re) after = re->head0;
         const unsigned long long hi = m_live & gt_mask;
         const uint32_t src = hi ? (uint32_t)__builtin_ctzll(hi) : lane;
         const uint32_t nf = __shfl(f1, src, kWave);
@@ -1536,6 +1540,37 @@ __global__ __launch_bounds__(256) void k_first_pick(unsigned long long *best_ptr
         fs->pos_key = ~0ull;
         fs->n_tie = 0;
     }
+    if (nt) for (uint32_t i = threadIdx.x; i < kFirstBitmapWords; i += blockDim.x) fs->bitmap[i] = 0;
+}
+
+// Sharded stream: every rank found the earliest tied pair of ITS shard; the ranks' shards follow each other in rank order,
+// so the pair that comes first in the corpus is the hit of the lowest rank that has one.  Each rank writes (found, tile,
+// key) into its own slot of a small array whose other slots it leaves zero -- the transport's sum is then an all-gather --
+// and k_first_pick_global takes the first slot that says "found".  Slot r = words [2 + 8 r, 2 + 8 r + 3) of a buffer of
+// exchange_header_words(n_ranks) words (the layout of the rank-edge header, so that transports see a size they know).
+__global__ void k_first_publish(const FirstState *fs, uint32_t *xf, int rank) {
+    if (blockIdx.x || threadIdx.x) return;
+    const unsigned long long pk = fs->pos_key;
+    const bool found = fs->n_tie > 1 && pk != ~0ull;
+    xf[2 + 8 * rank + 0] = found ? 1u : 0u;
+    xf[2 + 8 * rank + 1] = found ? (uint32_t)(pk >> 32) : 0u;
+    xf[2 + 8 * rank + 2] = found ? (uint32_t)pk : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_first_pick_global(unsigned long long *best_ptr, FirstState *fs, uint32_t *xf,
+                                                           int n_ranks, uint32_t xf_words) {
+    __shared__ uint32_t nt;
+    if (threadIdx.x == 0) {
+        nt = fs->n_tie;
+        if (nt > 1) {
+            for (int r = 0; r < n_ranks; ++r)
+                if (xf[2 + 8 * r]) { *best_ptr = pack_best((int32_t)(*best_ptr >> 32), xf[2 + 8 * r + 2]); break; }
+        }
+        fs->pos_key = ~0ull;
+        fs->n_tie = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < xf_words; i += blockDim.x) xf[i] = 0;
     if (nt) for (uint32_t i = threadIdx.x; i < kFirstBitmapWords; i += blockDim.x) fs->bitmap[i] = 0;
 }
 
@@ -4834,16 +4869,21 @@ void launch_first_init(hipStream_t s, void *fs) {
 
 void launch_first_tiebreak(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best, void *fs_,
                            const uint16_t *tok, const uint16_t *tok_other, const TileSum *sums, uint32_t n_tiles,
-                           uint32_t endbit, int n_cus, int seq) {
+                           uint32_t endbit, int n_cus, int seq, int phase, const RankEdge *right_edge, uint32_t *xf, int rank,
+                           int n_ranks) {
     FirstState *fs = static_cast<FirstState *>(fs_);
-    const uint32_t n_blocks = (t.ecap + kBlockSize - 1) >> kBlockShift;
-    hipLaunchKernelGGL(k_first_gather, dim3(blocks_for(n_blocks, 4, 2048)), dim3(256), 0, s, t, ctl, best, fs, seq);
-    if (n_tiles) {
-        const dim3 grid(tile_grid(n_tiles, n_cus, 8)), block(kMergeThreads);
-        MBPE_BY_MODE(endbit, hipLaunchKernelGGL(k_first_pos<M>, grid, block, 0, s, tok, tok_other, sums, n_tiles, t, best, fs,
-                                                ctl, seq));
+    if (phase != 2) {
+        const uint32_t n_blocks = (t.ecap + kBlockSize - 1) >> kBlockShift;
+        hipLaunchKernelGGL(k_first_gather, dim3(blocks_for(n_blocks, 4, 2048)), dim3(256), 0, s, t, ctl, best, fs, seq);
+        if (n_tiles) {
+            const dim3 grid(tile_grid(n_tiles, n_cus, 8)), block(kMergeThreads);
+            MBPE_BY_MODE(endbit, hipLaunchKernelGGL(k_first_pos<M>, grid, block, 0, s, tok, tok_other, sums, n_tiles, t, best, fs,
+                                                    ctl, seq, right_edge));
+        }
     }
-    hipLaunchKernelGGL(k_first_pick, dim3(1), dim3(256), 0, s, best, fs, ctl, seq);
+    if (phase == 0) hipLaunchKernelGGL(k_first_pick, dim3(1), dim3(256), 0, s, best, fs, ctl, seq);
+    else if (phase == 1) hipLaunchKernelGGL(k_first_publish, dim3(1), dim3(64), 0, s, fs, xf, rank);
+    else hipLaunchKernelGGL(k_first_pick_global, dim3(1), dim3(256), 0, s, best, fs, xf, n_ranks, exchange_header_words(n_ranks));
 }
 
 // runs of t before every tile, for the (t,t) pair of a single merge or the (t,t) member(s) of a batch

@@ -281,7 +281,12 @@ void launch_first_init(hipStream_t s, void *fs);
 // buffers 0 / 1 (ctl->cur picks), and the kernels only work when the selection flagged a tie (ctl->first_tie)
 void launch_first_tiebreak(hipStream_t s, PairTable t, const DevCtl *ctl, unsigned long long *best, void *fs,
                            const uint16_t *tok, const uint16_t *tok_other, const TileSum *sums, uint32_t n_tiles,
-                           uint32_t endbit, int n_cus, int seq);
+                           uint32_t endbit, int n_cus, int seq,
+                           int phase = 0 /* 0: one rank -- gather, position, pick.  Sharded stream: 1 = gather, position, publish
+                                            this rank's earliest hit in its slot of xf; [sum xf over the ranks]; 2 = pick the
+                                            hit of the lowest rank that has one */,
+                           const RankEdge *right_edge = nullptr, uint32_t *xf = nullptr /* exchange_header_words(n_ranks) */,
+                           int rank = 0, int n_ranks = 1);
 
 // one merge pass over the stream, in place; new summaries of changed tiles go
 // to `side`, their bits are set in `chg` (launch_apply folds them into sums)

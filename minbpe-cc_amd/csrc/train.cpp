@@ -142,6 +142,7 @@ struct mbpe_ctx {
     uint32_t *pc_scratch = nullptr;   // pair-count scan: per-workgroup histogram snapshots (kept for the context's life)
     uint32_t *pc_bp = nullptr;        // mbpe_pair_count_u8: the 65,536-entry result table
     void *first_state = nullptr;      // `first` tie-break scratch (training)
+    uint32_t *xf = nullptr;           // `first` on a sharded stream: every rank's earliest tied pair (hdr_words, see k_first_publish)
 
     // slot stream
     uint16_t *tok[2] = {nullptr, nullptr};
@@ -333,6 +334,7 @@ void free_training(mbpe_ctx *c) {
     tfree(c, c->bp); tfree(c, c->ctl); tfree(c, c->best); tfree(c, c->xb); tfree(c, c->xb0);
     tfree(c, c->d_left); tfree(c, c->d_right); tfree(c, c->bs); tfree(c, c->sel); tfree(c, c->seq_flags); tfree(c, c->run_in);
     tfree(c, c->first_state);
+    tfree(c, c->xf);
     tfree(c, c->wtok[0]); tfree(c, c->wtok[1]); tfree(c, c->wval); tfree(c, c->wscratch);
     tfree(c, c->wtab.keys); tfree(c, c->wtab.cnts); tfree(c, c->wctl); tfree(c, c->wbest); tfree(c, c->warg);
     c->wtab = {};
@@ -838,6 +840,10 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     if (c->opt_first) {
         HIPCHK(tmalloc(c, &c->first_state, first_state_bytes()));
         launch_first_init(c->stream, c->first_state);
+        if (is_multi(c)) {
+            HIPCHK(tmalloc(c, &c->xf, (size_t)c->hdr_words * 4));
+            HIPCHK(hipMemsetAsync(c->xf, 0, (size_t)c->hdr_words * 4, c->stream));
+        }
     }
     c->k_upper = 0;
     c->bp = nullptr;   // the byte-pair table lives at the front of xb0
@@ -905,7 +911,11 @@ static void update_hot_possible(mbpe_ctx *c, unsigned long long top_count, uint6
     c->hot_possible = !(live > eaten && top_count * 8192ull < (live - eaten) * (unsigned long long)std::max(1, c->n_ranks));
 }
 
-static int begin_finish(mbpe_ctx *c) {
+// `first` on a sharded stream: the position tie-break needs one more exchange (every rank's earliest tied pair), so the
+// finish of a begin / of a step comes in two parts around it
+static inline bool first_sharded(const mbpe_ctx *c) { return c->opt_first && is_multi(c); }
+
+static void begin_finish_a(mbpe_ctx *c) {
     const uint32_t endbit = endbit_of(c);
     if (is_multi(c)) {
         uint32_t *hdr = c->xb0 + 65536;
@@ -916,7 +926,14 @@ static int begin_finish(mbpe_ctx *c) {
     launch_argmax(c->stream, c->tab, c->ctl, c->best, use_hier(c));
     if (c->opt_first)
         launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best, c->first_state, c->tok[c->cur], nullptr, c->sums, c->n_tiles,
-                              endbit, c->n_cus, 0);
+                              endbit, c->n_cus, 0, first_sharded(c) ? 1 : 0, first_sharded(c) ? c->d_right : nullptr, c->xf,
+                              c->rank, std::max(1, c->n_ranks));
+}
+
+static int begin_finish_b(mbpe_ctx *c) {
+    if (first_sharded(c))
+        launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best, c->first_state, c->tok[c->cur], nullptr, c->sums, c->n_tiles,
+                              endbit_of(c), c->n_cus, 0, 2, nullptr, c->xf, c->rank, std::max(1, c->n_ranks));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     int rc = sync_ctl(c);
     if (rc != MBPE_OK) return rc;
@@ -929,6 +946,18 @@ static int begin_finish(mbpe_ctx *c) {
     c->begun = true;
     c->stats.ms_steps = 0;
     return MBPE_OK;
+}
+
+static int comm_allreduce(mbpe_ctx *c, uint32_t *buf, size_t count);   // RCCL (below)
+
+// (one GPU, or several over RCCL; with an external transport the two parts are driven by mbpe_comm_exchange_done)
+static int begin_finish(mbpe_ctx *c) {
+    begin_finish_a(c);
+    if (first_sharded(c)) {
+        const int rc = comm_allreduce(c, c->xf, c->hdr_words);
+        if (rc != MBPE_OK) return rc;
+    }
+    return begin_finish_b(c);
 }
 
 static void step_local(mbpe_ctx *c, int ev_slot) {
@@ -947,7 +976,7 @@ static void step_local(mbpe_ctx *c, int ev_slot) {
     }
 }
 
-static void step_finish(mbpe_ctx *c) {
+static void step_finish_a(mbpe_ctx *c) {
     const uint32_t X = 256 + c->k;
     const bool multi = is_multi(c);
     launch_apply(c->stream, c->tab, c->ctl, c->best + c->k, X, c->LR, multi ? c->xb : nullptr, c->sums, c->side,
@@ -956,8 +985,25 @@ static void step_finish(mbpe_ctx *c) {
     launch_argmax(c->stream, c->tab, c->ctl, c->best + c->k + 1, use_hier(c));
     if (c->opt_first)
         launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best + c->k + 1, c->first_state, c->tok[c->cur], nullptr, c->sums,
-                              c->n_tiles, endbit_of(c), c->n_cus, 0);
+                              c->n_tiles, endbit_of(c), c->n_cus, 0, first_sharded(c) ? 1 : 0,
+                              first_sharded(c) ? c->d_right : nullptr, c->xf, c->rank, std::max(1, c->n_ranks));
+}
+
+static void step_finish_b(mbpe_ctx *c) {
+    if (first_sharded(c))
+        launch_first_tiebreak(c->stream, c->tab, c->ctl, c->best + c->k + 1, c->first_state, c->tok[c->cur], nullptr, c->sums,
+                              c->n_tiles, endbit_of(c), c->n_cus, 0, 2, nullptr, c->xf, c->rank, std::max(1, c->n_ranks));
     c->k++;
+}
+
+static int step_finish(mbpe_ctx *c) {       // (one GPU, or several over RCCL)
+    step_finish_a(c);
+    if (first_sharded(c)) {
+        const int rc = comm_allreduce(c, c->xf, c->hdr_words);
+        if (rc != MBPE_OK) return rc;
+    }
+    step_finish_b(c);
+    return MBPE_OK;
 }
 
 // words of xb a sequence has to exchange: both headers + the LR rows of its n_pairs members, lr_pitch(ids) cells each
@@ -989,7 +1035,8 @@ static int seq_info_wait(mbpe_ctx *c, uint32_t *ids, uint32_t *n_pairs) {
 // (`first` mode decides between equal counts by stream position: batches only hold pairs whose counts nothing else
 //  shares -- k_sel_pick, k_validate -- and a pair with a shared count goes alone, after the position tie-break)
 static inline bool use_batches(const mbpe_ctx *c) {
-    return c->opt_multi_merge != 0 && (!c->opt_first || (c->opt_first_batches && !c->first_legacy));
+    // (`first` on a sharded stream: one merge per pass, the position tie-break is an exchange of its own)
+    return c->opt_multi_merge != 0 && (!c->opt_first || (c->opt_first_batches && !c->first_legacy && !is_multi(c)));
 }
 
 // Small corpora: a sequence is ~25 launches of which ~16 return at once (the device decides which stream kernel of which
@@ -1124,8 +1171,6 @@ static uint32_t seqs_per_sync(const mbpe_ctx *c) {
     return (uint32_t)g;
 }
 
-static int comm_allreduce(mbpe_ctx *c, uint32_t *buf, size_t count);   // RCCL (below)
-
 // housekeeping between batches: errors, holes, table headroom (h_ctl must be current)
 static int after_batch(mbpe_ctx *c) {
     c->n_valid = c->k;
@@ -1165,10 +1210,6 @@ int mbpe_train_begin(mbpe_ctx *c, uint32_t vocab_size) {
         }
         c->wide = true;
         vocab_size = c->opt_wide_from >= 0 ? (uint32_t)std::min<int64_t>(256 + c->opt_wide_from, vmax) : vmax;
-    }
-    if (c->opt_first && is_multi(c)) {
-        mbpe_host::set_last_error("conflict_resolution first: one GPU only");
-        return MBPE_ERR_STATE;
     }
     HIPCHK(hipSetDevice(c->device));
     int rc = begin_local(c, vocab_size);
@@ -1416,7 +1457,8 @@ static int train_steps16(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_done_out
                 rc = comm_allreduce(c, c->xb, step_exchange_words(c));
                 if (rc != MBPE_OK) return rc;
             }
-            step_finish(c);
+            rc = step_finish(c);
+            if (rc != MBPE_OK) return rc;
         }
         HIPCHK(hipEventRecord(c->ev1, c->stream));
         rc = sync_ctl(c);
@@ -1634,6 +1676,7 @@ int mbpe_comm_exchange_buffer(mbpe_ctx *c, void **dev_ptr_out, uint64_t *n_u32_o
         }
         return MBPE_OK;
     case 4: *dev_ptr_out = c->xb; *n_u32_out = c->hdr_words; return MBPE_OK;   // rank edges
+    case 5: case 6: *dev_ptr_out = c->xf; *n_u32_out = c->hdr_words; return MBPE_OK;   // `first`: the ranks' earliest tied pairs
     default: break;
     }
     mbpe_host::set_last_error("no exchange pending");
@@ -1645,11 +1688,31 @@ int mbpe_comm_exchange_done(mbpe_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     if (c->pending == 1) {
         c->pending = 0;
-        return begin_finish(c);
+        begin_finish_a(c);
+        if (first_sharded(c)) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->pending = 6;
+            return MBPE_NEED_EXCHANGE;
+        }
+        return begin_finish_b(c);
+    }
+    if (c->pending == 6) {
+        c->pending = 0;
+        return begin_finish_b(c);
     }
     if (c->pending == 2) {
         c->pending = 0;
-        step_finish(c);
+        step_finish_a(c);
+        if (first_sharded(c)) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->pending = 5;
+            return MBPE_NEED_EXCHANGE;
+        }
+        c->pending = 5;            // (falls through to the second part)
+    }
+    if (c->pending == 5) {
+        c->pending = 0;
+        step_finish_b(c);
         int rc = sync_ctl(c);
         if (rc != MBPE_OK) return rc;
         HIPCHK(hipGetLastError());

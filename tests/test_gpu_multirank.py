@@ -78,8 +78,13 @@ def _train_sharded(data, cuts, vocab, chunk_off=None, decode_check=False):
             t.load_corpus(data[lo:hi], off)
         codes = [t.train_begin(vocab) for t in trainers]
         assert all(c == mbpe.NEED_EXCHANGE for c in codes)
-        _allreduce(trainers)
-        assert all(t.exchange_done() == mbpe.OK for t in trainers)
+        n_begin = 0
+        while codes[0] == mbpe.NEED_EXCHANGE:       # (the byte-pair tables; with `first`: then the earliest tied pairs)
+            assert all(c == mbpe.NEED_EXCHANGE for c in codes)
+            _allreduce(trainers)
+            codes = [t.exchange_done() for t in trainers]
+            n_begin += 1
+        assert all(c == mbpe.OK for c in codes) and n_begin == (2 if EXTRA_OPTS.get("conflict_resolution", 1) == 0 else 1)
         del EXCHANGES[:]
         codes = [t.train_steps(vocab - 256) for t in trainers]
         while codes[0] == mbpe.NEED_EXCHANGE:
@@ -240,6 +245,57 @@ def test_fuzz_sharded(seed):
         R = int(rng.integers(2, 5))
         cuts = sorted(set(int(x) for x in rng.integers(1, len(data), size=R - 1)))
         _check(data.tobytes(), cuts, 256 + int(rng.integers(5, 120)))
+
+
+def _check_first(data, cuts, vocab, chunk_off=None):
+    """The `first` tie-break on a sharded stream: every rank must take the reference's choice -- among the pairs of
+    maximal count the one whose first occurrence comes first in the WHOLE corpus (PairCount.h:65-74, :141-166), which
+    may lie in another rank's shard or straddle two."""
+    global EXTRA_OPTS
+    want_m, want_c = O.train(data, vocab, chunk_off, mode=O.FIRST)
+    EXTRA_OPTS = dict(EXTRA_OPTS, conflict_resolution=0)
+    try:
+        results, streams, tables = _train_sharded(data, cuts, vocab, chunk_off)
+    finally:
+        EXTRA_OPTS = {k: v for k, v in EXTRA_OPTS.items() if k != "conflict_resolution"}
+    for m, c in results:
+        assert m.tolist() == want_m.tolist()
+        assert c.tolist() == want_c.tolist()
+    st = O.State(data, chunk_off, mode=O.FIRST)
+    for i, (a, b) in enumerate(want_m):
+        st.merge(int(a), int(b), 256 + i)
+    assert np.array_equal(np.concatenate(streams), st.stream()[0])
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_first_mode_sharded(R):
+    # ties everywhere (repeated blocks, small alphabets): the earliest occurrence decides, in whichever shard it lies
+    rng = np.random.default_rng(900 + R)
+    for case in range(6):
+        n = int(rng.integers(200, 20000))
+        if case % 2:
+            blk = rng.integers(97, 110, size=int(rng.integers(3, 120)), dtype=np.uint8)
+            data = np.tile(blk, n // len(blk) + 1)[:n]
+        else:
+            data = rng.integers(97, 97 + int(rng.choice([2, 3, 5, 12])), size=n, dtype=np.uint8)
+        cuts = sorted(set(int(x) for x in rng.integers(1, len(data), size=R - 1)))
+        while len(cuts) < R - 1:
+            cuts = sorted(set(cuts + [int(rng.integers(1, len(data)))]))
+        _check_first(data.tobytes(), cuts, 256 + int(rng.integers(5, 60)))
+
+
+def test_first_mode_sharded_tie_across_the_cut():
+    # "abab...": (a,b) and (b,a) tie; the first occurrence of the winner straddles the cut, or lies right behind it
+    _check_first(b"ab" * 300, [1], 256 + 6)
+    _check_first(b"ab" * 300, [2], 256 + 6)
+    _check_first(b"cd" * 5 + b"ab" * 5 + b"cd" * 5 + b"ab" * 5, [10], 256 + 6)       # every "ab" lies in the right shard
+    _check_first(b"xyxy" + b"ab" * 200 + b"xy" * 198, [3, 404], 256 + 8)
+
+
+def test_first_mode_sharded_text_chunked():
+    data = read_data("taylorswift.txt")[:40000]
+    off = mbpe.presplit(O.GPT4_SPLIT_PATTERN, data)
+    _check_first(data, [int(off[len(off) // 3]), int(off[2 * len(off) // 3])], 256 + 60, off)
 
 
 def test_rccl_single_rank_communicator():
