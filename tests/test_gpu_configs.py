@@ -137,6 +137,45 @@ def test_config4_merge_order_at_checkpoints_1gib(dev):
         assert len(m) == total and C.counts_nonincreasing(c)
 
 
+def _pair_table_torch(corpus):
+    """count[(first << 8) | second] of a uint8 device tensor, piecewise."""
+    n = corpus.numel()
+    table = torch.zeros(65536, dtype=torch.int64, device=corpus.device)
+    step = 1 << 28
+    for lo in range(0, n - 1, step):
+        hi = min(lo + step, n - 1)
+        a = corpus[lo:hi].long()
+        b = corpus[lo + 1:hi + 1].long()
+        table += torch.bincount(a * 256 + b, minlength=65536)
+        del a, b
+    return table
+
+
+def test_pair_count_void_segments_1gib(dev):
+    """The pair-count scan at 1 GiB (128 iterations per workgroup: a first segment of 64, then the rest): uniform bytes
+    (both segments pass their checksums), then the same corpus with the end of every other workgroup's range one repeated
+    byte (> 65,535 equal pairs in the second segment: a 16-bit counter wraps, the segment is void, restored from its
+    snapshot and recounted with sweeps), twice in a row; against a count done with torch on the device."""
+    from bench import splitmix64_device
+    n = 1 << 30
+    keep, corpus = splitmix64_device(7, n, dev)
+    torch.cuda.synchronize()
+    with mbpe.Trainer(0) as tr:
+        tr.load_corpus_device(corpus.data_ptr(), n, keep=keep)
+        want = _pair_table_torch(corpus).cpu().numpy()
+        for _ in range(2):
+            assert np.array_equal(tr.pair_count_u8().astype(np.int64), want)
+        grid = torch.cuda.get_device_properties(0).multi_processor_count
+        per = n // grid
+        for w in range(0, grid, 2):
+            corpus[(w + 1) * per - per // 6:(w + 1) * per - 40000] = 7      # (inside the last eighth and a bit more)
+        torch.cuda.synchronize()
+        want = _pair_table_torch(corpus).cpu().numpy()
+        assert int(want[(7 << 8) | 7]) > 1 << 26
+        for _ in range(2):
+            assert np.array_equal(tr.pair_count_u8().astype(np.int64), want)
+
+
 def test_config4_order_inside_large_batches_4gib(dev):
     """BASELINE config 4 at its full size with default options: 48 checkpoints at RANDOM merge counts, three quarters of
     them inside merges 300..17,000 -- the phase whose batches hold 1,000-4,096 pairs (the 128 x 128 pairs of two halves
