@@ -451,12 +451,14 @@ def main():
 
     # ---- pair-count scan (the north star's graded kernel), timed last: an idle chip needs ~25 launches of this
     # kernel (some tens of milliseconds of work) to reach its sustained clock -- launch times fall by a fifth
-    # meanwhile -- and by now the process has kept it busy for a while.  5 launches of warm-up, then 30 launches in
+    # meanwhile; the checks before this point keep it busy with other kernels, and the first ten launches after them
+    # still run 3-4 % slower than the next twenty.  25 launches of warm-up, then 30 launches in
     # three groups of ten back to back; every dispatch carries its own start / stop events (hipExtLaunchKernelGGL),
     # so avg_launch_ms is the mean KERNEL duration -- no gap between launches, no marker -- which is what rocprofv3
     # reports per dispatch.  (ms_bracket: the same launches between one pair of stream events per group, gaps included.)
     scan_ms, scan_bracket = [], []
-    for _ in range(5):
+    tr.set_option("pc_repeat", 5)
+    for _ in range(5):                       # 25 launches of warm-up in five groups (their means are reported too)
         tr.pair_count_u8(want_table=False)
         scan_ms.append(tr.stats()["ms_pair_count_kernel"])
     tr.set_option("pc_repeat", 10)
@@ -534,12 +536,12 @@ def main():
                 "traffic": pmc_traffic("k_pair_count_u8", args.config, total_bytes, vocab, world),
                 "algorithmic_bytes_per_launch": hi - lo,
                 "avg_launch_ms": scan_ms_avg,
-                "avg_launch_ms_is": "mean kernel duration of launches 6-35 of 35 (three groups of ten launches back to back), "
-                                    "each dispatch timed by its own start/stop events (hipExtLaunchKernelGGL), after 5 "
-                                    "warm-up launches, taken after the training runs of this process (chip at its "
-                                    "sustained clock)",
+                "avg_launch_ms_is": "mean kernel duration of launches 26-55 of 55 (three groups of ten launches back to back), "
+                                    "each dispatch timed by its own start/stop events (hipExtLaunchKernelGGL), after 25 "
+                                    "warm-up launches (the kernel's sustained clock: an idle or differently loaded chip "
+                                    "takes ~25 launches of it to get there), taken after the training runs of this process",
                 "launch_ms_all": [round(x, 4) for x in scan_ms],
-                "launch_ms_all_is": "5 single launches (warm-up), then the mean kernel duration of each group of ten",
+                "launch_ms_all_is": "mean kernel duration of five warm-up groups of five launches, then of each timed group of ten",
                 "ms_bracket": [round(x, 4) for x in scan_bracket],
                 "ms_bracket_is": "the same groups of ten between ONE pair of stream events, per launch: gaps between "
                                  "launches included",

@@ -216,8 +216,7 @@ struct mbpe_ctx {
     int64_t opt_first = 0;          // 1: `first` tie-break (insertion order, PairCount.h:65-74) instead of lexical
     int64_t opt_pc_repeat = 1;      // mbpe_pair_count_u8 without an output table: launches per call (timing)
     uint32_t k_upper = 0;           // host-side upper bound of the device's k_done
-    int sel_attempts = 3;           // gather + pick attempts enqueued per selection: 1 while the last group of sequences
-                                    //   neither retried nor fell back to the bound-walking kernel (4 empty launches less)
+    int sel_attempts = 3;           // gather + pick attempts enqueued per selection (see train_steps_batched)
     uint32_t max_batch_eff = kBatchMax, adj_pitch = kBatchMax;   // (set by mbpe_train_begin: see begin_local)
     // multi-GPU: what the selection of the sequence in flight decided (k_done, k_limit, batch_n, commit_n of DevCtl),
     // read back while its stream pass runs, so that exactly the cells the batch can touch are exchanged
@@ -1328,8 +1327,10 @@ static int train_steps_batched(mbpe_ctx *c, uint32_t n_steps, uint32_t *steps_do
             }
             c->stats.merge_launches += c->h_ctl.n_batches - batches_before;   // sequences that did work
         }
-        // (the selection's second and third attempts: only enqueued while the last group needed one, or the fallback)
-        c->sel_attempts = (c->h_ctl.n_sel_retry + c->h_ctl.n_sel_fallback != retry_before || c->comm_external) ? 3 : 1;
+        // (Round 4 tried to enqueue the selection's second and third attempts only while the last group had needed one:
+        //  a selection that then needs them falls back to the bound-walking kernel, whose batches are a few pairs -- with a
+        //  host round trip per sequence 138 passes instead of 66 on the benchmark workload.  All three, always.)
+        (void)retry_before;
         const uint32_t before = c->k;
         c->k = c->h_ctl.k_done;
         if (c->k) {             // the count of the latest merge bounds every later one
