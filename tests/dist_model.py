@@ -426,6 +426,53 @@ class Shard:
             self.k += 1
         return self.merges, self.counts
 
+    # -- `first` tie-break on a sharded stream (k_first_gather / k_first_pos / k_first_publish / k_first_pick_global) --
+    def argmax_first(self):
+        """Among the pairs of maximal count the one whose first occurrence comes first in the whole corpus
+        (PairCountInsertOrder on a table rebuilt per merge: PairCount.h:65-74, :141-166; Tokenizer.h:581-585).  Every rank
+        finds the earliest tied pair of ITS shard -- the pair of its last token takes its second token from the right
+        neighbour's edge -- and publishes (found, position, key) in its slot of a rank-indexed array; the sum over the
+        ranks is an all-gather, and the hit of the lowest rank that has one wins: shards follow each other in rank order.
+        A count of 0 means no pair is left: the reference's loop breaks (Tokenizer.h:586-588)."""
+        m = max(self.table.values(), default=0)
+        if m <= 0:
+            return None
+        ties = {k for k, c in self.table.items() if c == m}
+        key = min(ties)
+        if len(ties) > 1:                     # (the table is replicated: every rank sees the same ties)
+            t, n, idm = self.toks, len(self.toks), self.idmask
+            slot = [0, 0, 0]
+            for i in range(n):
+                if t[i] & self.endbit:
+                    continue
+                nx = t[i + 1] if i + 1 < n else self.right[0]
+                if nx == HOLE:
+                    continue
+                kk = ((t[i] & idm) << 16) | (nx & idm)
+                if kk in ties:
+                    slot = [1, i, kk]
+                    break
+            buf = np.zeros(self.hdr, dtype=np.int64)
+            buf[2 + 8 * self.rank:2 + 8 * self.rank + 3] = slot
+            buf = self.allreduce(buf)
+            for r in range(self.world):
+                if buf[2 + 8 * r]:
+                    key = int(buf[2 + 8 * r + 2])
+                    break
+        return key >> 16, key & 0xFFFF, m
+
+    def train_first(self, vocab_size):
+        self.begin()
+        for i in range(256, vocab_size):
+            top = self.argmax_first()
+            if top is None:
+                break
+            a, b, c = top
+            self.merges.append((a, b))
+            self.counts.append(c)
+            self.merge(a, b, i)
+        return self.merges, self.counts
+
     def train(self, vocab_size):
         self.begin()
         for i in range(256, vocab_size):

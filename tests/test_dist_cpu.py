@@ -40,7 +40,7 @@ def _cases():
     return cases
 
 
-def _worker(rank, world, port, q, batched=False):
+def _worker(rank, world, port, q, batched=False, first=False):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "minbpe-cc_amd", "python"))
     sys.path.insert(0, HERE)
@@ -80,13 +80,15 @@ def _worker(rank, world, port, q, batched=False):
                     assert words == sh.hdr + (sh.BATCH_MAX + sh.BATCH_MAX ** 2) + 2 * nb * ((ids + 63) & ~63)
                 if ci in (0, 11, 12):       # (random bytes, text: the tiny-alphabet cases have nothing independent to batch)
                     assert sum(nb >= 2 for nb, _, _ in sh.exchanged) >= 3, "case %d ran no batches" % ci
+            elif first:
+                merges, counts = sh.train_first(vocab)
             else:
                 merges, counts = sh.train(vocab)
-            want_m, want_c = O.train(data, vocab, off)
+            want_m, want_c = O.train(data, vocab, off, mode=O.FIRST if first else O.LEXICAL)
             assert [list(m) for m in merges] == want_m.tolist(), "case %d merges" % ci
             assert list(counts) == want_c.tolist(), "case %d counts" % ci
             # the shards, concatenated, are the oracle's final stream
-            st = O.State(data, off)
+            st = O.State(data, off, mode=O.FIRST if first else O.LEXICAL)
             for i, (a, b) in enumerate(want_m):
                 st.merge(int(a), int(b), 256 + i)
             mine = np.array([t & sh.idmask for t in sh.toks], dtype=np.int64)
@@ -121,6 +123,25 @@ def test_sharded_protocol_over_gloo(world, batched):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, batched)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_first_tie_break_over_gloo(world):
+    """The `first` tie-break (the reference CLI's default) on a sharded stream: one merge per exchange of count deltas
+    plus, when counts tie, one small exchange of every rank's earliest tied pair (dist_model.Shard.argmax_first: the
+    protocol of k_first_pos / k_first_publish / k_first_pick_global) -- against the oracle's rebuilt-table mode."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, False, True)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
