@@ -107,3 +107,20 @@ def test_e2e_gpt4_vocab_40000(tmp_path):
     _run("-e", "-i", src, "-m", model, "-o", enc)
     _run("-d", "-i", enc, "-m", model, "-o", dec)
     assert dec.read_bytes() == data
+
+
+def test_e2e_gpt4_vocab_100000(tmp_path):
+    # `--vocab-size 100000 --encoder gpt4`: a GPT-4-size vocabulary, beyond the 16-bit slot format (the reference's Token
+    # is a uint32_t, Tokenizer.h:37-38): the training continues on 32-bit tokens (csrc/wide.hip).  Model bytes against
+    # the oracle, then the reference's round trip.
+    model, enc, dec = tmp_path / "huge-model", tmp_path / "enc", tmp_path / "dec"
+    src = os.path.join(DATA, "taylorswift.txt")
+    out = _run("-t", "-i", src, "-m", model, "-c", "lexical", "--vocab-size", 100000)
+    assert "Writing model..." in out
+    data = read_data("taylorswift.txt")
+    want_m, _ = O.train(data, 100000, mbpe.presplit(O.GPT4_SPLIT_PATTERN, data))
+    assert len(want_m) == 100000 - 256
+    assert model.read_bytes() == O.model_bytes(O.GPT4_SPLIT_PATTERN, want_m)
+    _run("-e", "-i", src, "-m", model, "-o", enc)
+    _run("-d", "-i", enc, "-m", model, "-o", dec)
+    assert dec.read_bytes() == data
