@@ -279,6 +279,12 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *                   mbpe_train_begin only
  *   "time_kernels"  1 = bracket every merge kernel with HIP events on the
  *                   context's stream; totals appear in mbpe_stats
+ *   "lockstep"      how the host enqueues batch sequences: 1 = it waits for every selection and enqueues only the
+ *                   kernels that sequence needs (one event wait per sequence, ~12 launches instead of ~27), 0 = it
+ *                   enqueues whole groups of sequences with every kernel variant and the device decides which work;
+ *                   -1 (default): 1 for streams of up to 32 Mi slots on one rank, 0 otherwise.  Same results.
+ *   "wide_from"     tests: hand over to the 32-bit continuation after this many merges whatever the vocabulary
+ *                   (-1, the default: where the 16-bit slot format ends); read by mbpe_train_begin
  */
 MBPE_API int mbpe_set_option(mbpe_ctx *ctx, const char *name, int64_t value);
 
