@@ -3182,7 +3182,8 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
                                                uint32_t X0, uint32_t tile, TileSum *sout, uint32_t *hdr_adj, uint32_t *LR,
                                                DC &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
                                                __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage,
-                                               uint32_t *chg, bool renamed, TTInfo *ti, bool &need_rename);
+                                               uint32_t *chg, bool renamed, TTInfo *ti, bool &need_rename,
+                                               __amdgpu_buffer_rsrc_t t_rsrc = __amdgpu_buffer_rsrc_t(), bool use_t = false);
 
 template <int MODE, bool HOT, bool TT, int DIAG = 0>
 __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0, const uint16_t *tok1,
@@ -3191,7 +3192,8 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
                                                               uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
                                                               const DevCtl *ctl, const RankEdge *le,
                                                               const RankEdge *re,
-                                                              const uint32_t *__restrict__ run_in, int hot_launched) {
+                                                              const uint32_t *__restrict__ run_in, int hot_launched,
+                                                              uint32_t *T) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     __shared__ BatchLutMem lut_mem;
     const uint32_t lane = lane_id();
@@ -3220,6 +3222,9 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
     const __amdgpu_buffer_rsrc_t sums_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
     const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(LR, 0, 0xFFFFFFFCu, 0x00020000);
+    // (the pairs' byte x byte cell blocks: see k_pair_cells_fold; not with the delta cache of frequent pairs)
+    const bool use_t = T != nullptr && !HOT;
+    const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(T ? T : LR, 0, T ? 0xFFFFFFFCu : 0u, 0x00020000);
     TileIn t0 = tile_issue(tok, sums_rsrc, tile);
     TileIn t1 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + n_waves));
     bool v1 = (uint64_t)tile + n_waves < n_tiles;
@@ -3250,7 +3255,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
                 if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);      // ((t,t) members: every tile, as the chain-walking path did)
                 fused_tile_pf<MODE, 0, false, TT>(t0.q, s, h, rlane(t0.smw, 4), rlane(t0.smw, 5), rlane(t0.smw, 6), lut,
                                                   256u + ctl_k_done, tile, nullptr, hdr_adj, LR, dc, dc_on, rm_unused, ws_unused,
-                                                  lr_rsrc, adj_pitch, nullptr, chg, TT, &ti, no_rename);
+                                                  lr_rsrc, adj_pitch, nullptr, chg, TT, &ti, no_rename, t_rsrc, use_t);
             } else {
             if (TT) tt_rename<MODE>(s, h, ti, run_in[tile]);
             // first live token of the lanes after this one (exact), then the candidate
@@ -3460,7 +3465,8 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
                                                uint32_t X0, uint32_t tile, TileSum *sout, uint32_t *hdr_adj, uint32_t *LR,
                                                DC &dc, bool dc_on, uint32_t &wave_rm, bool &wrote_sum,
                                                __amdgpu_buffer_rsrc_t lr_rsrc, uint32_t adj_pitch, uint16_t *stage,
-                                               uint32_t *chg, bool renamed, TTInfo *ti, bool &need_rename) {
+                                               uint32_t *chg, bool renamed, TTInfo *ti, bool &need_rename,
+                                               __amdgpu_buffer_rsrc_t t_rsrc, bool use_t) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     constexpr uint32_t endbit = MODE == 1 ? kEndBit : 0u;
     constexpr uint32_t kNone = 0xFFFFu;          // "this slot starts no match" (batch indices are below kBatchMax)
@@ -3605,15 +3611,24 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
                 if (TT && renamed && (btok & idmask) >= idmask - (uint32_t)kTTMax)       // a match of a (t,t) member: count it
                     atomicAdd(&ti->cnt[idmask - 1u - (btok & idmask)], 1u);
                 if (DIAG != 2) {
-                    if (left_open<MODE>(p1)) {
-                        if (ppj != kNone) {      // ... (a', b') (a, b): (b', a) -> (X', X)
-                            atomicAdd(&hdr_adj[ppj * adj_pitch + ja], 1u);
-                            delta_add(lr_idx(pitch, self, ppj, 1), 0xFFFFFFFFu);     // takes back the R count of (a', b')
-                        } else {
-                            delta_add(lr_idx(pitch, p1 & idmask, ja, 0u), 1u);
+                    const bool lo = left_open<MODE>(p1), ro = right_open<MODE>(btok, n2);
+                    const uint32_t xl = p1 & idmask, yr = n2 & idmask;
+                    if (use_t && lo && ro && ppj == kNone && xl < 256u && yr < 256u) {
+                        // both neighbours are raw bytes and no match touches this one: ONE atomic on the pair's
+                        // byte x byte cell block instead of two on its L and R rows (k_pair_cells_fold adds the
+                        // block's row and column sums to the rows afterwards)
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, t_rsrc, ((ja << 16) | (xl << 8) | yr) << 2, 0, 0);
+                    } else {
+                        if (lo) {
+                            if (ppj != kNone) {      // ... (a', b') (a, b): (b', a) -> (X', X)
+                                atomicAdd(&hdr_adj[ppj * adj_pitch + ja], 1u);
+                                delta_add(lr_idx(pitch, self, ppj, 1), 0xFFFFFFFFu);     // takes back the R count of (a', b')
+                            } else {
+                                delta_add(lr_idx(pitch, xl, ja, 0u), 1u);
+                            }
                         }
+                        if (ro) delta_add(lr_idx(pitch, yr, ja, 1u), 1u);
                     }
-                    if (right_open<MODE>(btok, n2)) delta_add(lr_idx(pitch, n2 & idmask, ja, 1u), 1u);
                 }
             }
         }
@@ -3670,7 +3685,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                                                                uint32_t *hdr_adj, uint32_t *LR, DevCtl *ctl,
                                                                const RankEdge *le, const RankEdge *re,
                                                                uint32_t *hdr_m, const uint32_t *__restrict__ run_in,
-                                                               int hot_launched) {
+                                                               int hot_launched, uint32_t *T) {
     constexpr uint32_t idmask = MODE == 1 ? 0x7FFFu : 0xFFFFu;
     __shared__ BatchLutMem lut_mem;
     const uint32_t lane = lane_id();
@@ -3705,6 +3720,9 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     const __amdgpu_buffer_rsrc_t sums_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
     const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(LR, 0, 0xFFFFFFFCu, 0x00020000);
+    // (the pairs' byte x byte cell blocks: see k_pair_cells_fold; not with the delta cache of frequent pairs)
+    const bool use_t = T != nullptr && !HOT;
+    const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(T ? T : LR, 0, T ? 0xFFFFFFFCu : 0u, 0x00020000);
     const uint32_t adj_pitch = rfl(ctl->adj_pitch);
     // kDepth tiles are in flight behind the one being worked on (5 registers each)
 #ifndef MBPE_FUSED_DEPTH
@@ -3762,12 +3780,12 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
                 }
                 outq = fused_tile_pf<MODE, DIAG, true, TT>(t0.q, s, h, old_x, old_y, old_z, lut, X0, tile, sout, hdr_adj, LR, dc,
                                                            dc_on, wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage, chg, renamed, &ti,
-                                                           need_rename);
+                                                           need_rename, t_rsrc, use_t);
                 if (TT && need_rename) {             // (uniform, rare)
                     tt_rename<MODE>(s, h, ti, run_in[tile]);
                     outq = fused_tile_pf<MODE, DIAG, true, TT>(t0.q, s, h, old_x, old_y, old_z, lut, X0, tile, sout, hdr_adj, LR,
                                                                dc, dc_on, wave_rm, wrote_sum, lr_rsrc, adj_pitch, stage, chg, true,
-                                                               &ti, need_rename);
+                                                               &ti, need_rename, t_rsrc, use_t);
                 }
             } else {
             uint32_t lf, c_init, tile_first, cj[8];
@@ -3851,6 +3869,39 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
     if (lane == 0 && wave_rm) atomicAdd(&ctl->rm, wave_rm);
     if (TT) {                           // matches of the (t,t) member: its count is not simply the pair's count
         tt_flush(ti, hdr_m);
+    }
+}
+
+// The pairs' byte x byte cell blocks (round 4).  A match whose two neighbours are raw bytes and which no other match
+// touches costs the stream pass ONE scattered atomic, on cell T[j][x][y] of its pair's 256 x 256 block, instead of two
+// (L_j[x] and R_j[y]): in the passes of thousands of byte pairs, which their atomics bound, most
+// matches are of that kind.  This kernel adds every block's row sums to the pair's L row and its column sums to the R row
+// and clears the block, so that everything behind the pass -- validation, the table update, the exchange of several
+// ranks -- sees the rows it always saw.  One workgroup per pair at a time; 256 KiB read (and what was not zero cleared).
+__global__ __launch_bounds__(256) void k_pair_cells_fold(uint32_t *__restrict__ T, uint32_t *__restrict__ LR, const DevCtl *ctl) {
+    __shared__ uint32_t rows[256];
+    const uint32_t n = ctl->batch_n;
+    if (n < 2) return;
+    const uint32_t pitch = lr_pitch(256u + ctl->k_done);
+    const uint32_t t = threadIdx.x;
+    for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
+        uint32_t *tj = T + (size_t)j * 65536u;
+        rows[t] = 0;
+        __syncthreads();
+        uint32_t col = 0;
+#pragma unroll 8
+        for (uint32_t x = 0; x < 256u; ++x) {
+            const uint32_t v = tj[x * 256u + t];
+            if (__ballot(v != 0u) == 0ull) continue;          // (this wave's quarter of the row is empty)
+            if (v) tj[x * 256u + t] = 0;
+            col += v;
+            const uint32_t rs = wave_sum(v);
+            if (lane_id() == 0 && rs) atomicAdd(&rows[x], rs);
+        }
+        __syncthreads();
+        if (col) LR[lr_idx(pitch, t, j, 1u)] += col;             // R_j[y = t]
+        if (rows[t]) LR[lr_idx(pitch, t, j, 0u)] += rows[t];     // L_j[x = t]
+        __syncthreads();
     }
 }
 
@@ -4977,7 +5028,7 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
                         uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible, int only) {
+                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible, int only, uint32_t *T) {
     if (!n_tiles) return;
     static const int occ[3] = {resident_blocks(k_fused_batch<0, false, false, 0>, kLutThreads),
                                resident_blocks(k_fused_batch<1, false, false, 0>, kLutThreads),
@@ -4988,9 +5039,9 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
 #define MBPE_FUSED_DIAG_CASE(D)                                                                                            \
     if (diag == D && !endbit) {                                                                                            \
         hipLaunchKernelGGL((k_fused_batch<0, false, false, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,        \
-                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);                               \
+                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible, T);                               \
         hipLaunchKernelGGL((k_fused_batch<0, false, true, D>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles,         \
-                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);                               \
+                           chg, bs, hdr_adj, LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible, T);                               \
         return;                                                                                                            \
     }
     MBPE_FUSED_DIAG_CASE(2)
@@ -5004,23 +5055,23 @@ void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const Til
         // (only >= 0: exactly the instantiation the host knows this batch takes -- bit 0: (t,t) member, bit 1: frequent pair)
         if (only < 0 || only == 0)
             hipLaunchKernelGGL((k_fused_batch<M, false, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible, T);
         if (only < 0 || only == 1)
             hipLaunchKernelGGL((k_fused_batch<M, false, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible, T);
         if (only < 0 ? hot_possible != 0 : only == 2)
             hipLaunchKernelGGL((k_fused_batch<M, true, false>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible, T);
         if (only < 0 ? hot_possible != 0 : only == 3)
             hipLaunchKernelGGL((k_fused_batch<M, true, true>), grid, block, 0, s, tok0, tok1, sums, side, n_tiles, chg, bs, hdr_adj,
-                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible);
+                               LR, ctl, left_edge, right_edge, hdr_m, run_in, hot_possible, T);
     });
 }
 
 void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1, const TileSum *sums, uint32_t n_tiles,
                        uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj, uint32_t *LR,
                        const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                       int n_cus, const uint32_t *run_in, int hot_possible, int only) {
+                       int n_cus, const uint32_t *run_in, int hot_possible, int only, uint32_t *T) {
     if (!n_tiles) return;
     static const int occ[3] = {resident_blocks(k_scan_batch<0, false, false, 0>, kLutThreads),
                                resident_blocks(k_scan_batch<1, false, false, 0>, kLutThreads),
@@ -5031,7 +5082,7 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
 #define MBPE_SCAN_DIAG_CASE(D)                                                                                             \
     if (diag == D && !endbit) {                                                                                            \
         hipLaunchKernelGGL((k_scan_batch<0, false, false, D>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs,       \
-                           hdr_m, hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible);                                        \
+                           hdr_m, hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible, T);                                        \
         return;                                                                                                            \
     }
     MBPE_SCAN_DIAG_CASE(1)
@@ -5043,17 +5094,24 @@ void launch_scan_batch(hipStream_t s, const uint16_t *tok, const uint16_t *tok1,
     MBPE_BY_MODE(endbit, {
         if (only < 0 || only == 0)
             hipLaunchKernelGGL((k_scan_batch<M, false, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj,
-                               LR, ctl, left_edge, right_edge, run_in, hot_possible);
+                               LR, ctl, left_edge, right_edge, run_in, hot_possible, T);
         if (only < 0 || only == 1)
             hipLaunchKernelGGL((k_scan_batch<M, false, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m, hdr_adj,
-                               LR, ctl, left_edge, right_edge, run_in, hot_possible);
+                               LR, ctl, left_edge, right_edge, run_in, hot_possible, T);
         if (only < 0 ? hot_possible != 0 : only == 2)
             hipLaunchKernelGGL((k_scan_batch<M, true, false, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m,
-                               hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible);
+                               hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible, T);
         if (only < 0 ? hot_possible != 0 : only == 3)
             hipLaunchKernelGGL((k_scan_batch<M, true, true, 0>), grid, block, 0, s, tok, tok1, sums, n_tiles, chg, bs, hdr_m,
-                               hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible);
+                               hdr_adj, LR, ctl, left_edge, right_edge, run_in, hot_possible, T);
     });
+}
+
+void launch_pair_cells_fold(hipStream_t s, uint32_t *T, uint32_t *LR, const DevCtl *ctl, uint32_t n_hint) {
+    if (!T) return;
+    if (n_hint < 64u) n_hint = 64u;
+    if (n_hint > 1024u) n_hint = 1024u;
+    hipLaunchKernelGGL(k_pair_cells_fold, dim3(n_hint), dim3(256), 0, s, T, LR, ctl);
 }
 
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,

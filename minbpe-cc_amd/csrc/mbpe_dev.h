@@ -329,12 +329,19 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
 void launch_scan_batch(hipStream_t s, const uint16_t *tok0, const uint16_t *tok1, const TileSum *sums,
                        uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                        uint32_t *LR, const DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge,
-                       uint32_t endbit, int n_cus, const uint32_t *run_in, int hot_possible = 1, int only = -1);
+                       uint32_t endbit, int n_cus, const uint32_t *run_in, int hot_possible = 1, int only = -1,
+                       uint32_t *pair_cells = nullptr);
 // large batch (ctl->fused): count the deltas and write the merged stream to the other buffer
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
                         uint32_t n_tiles, uint32_t *chg, const BatchState *bs, uint32_t *hdr_adj, uint32_t *LR,
                         DevCtl *ctl, const RankEdge *left_edge, const RankEdge *right_edge, uint32_t endbit,
-                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible = 1, int only = -1);
+                        int n_cus, uint32_t *hdr_m, const uint32_t *run_in, int hot_possible = 1, int only = -1,
+                        uint32_t *pair_cells = nullptr);
+// pair_cells (optional, both passes above): 65,536 u32 cells per pair of the largest batch, all zero between sequences.  A
+// match whose two neighbours are raw bytes and which no other match touches then costs the pass one atomic (cell
+// [j][x][y]) instead of two (L_j[x], R_j[y]); launch_pair_cells_fold, right behind the pass, adds the blocks' row and
+// column sums to the LR rows and clears the blocks: everything after it sees the rows it always saw.
+void launch_pair_cells_fold(hipStream_t s, uint32_t *pair_cells, uint32_t *LR, const DevCtl *ctl, uint32_t n_hint);
 // k_delta_max + k_validate + k_apply_batch
 void launch_batch_tables(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, uint32_t *hdr_m, uint32_t *hdr_adj,
                          uint32_t *LR, uint32_t id_upper, uint32_t n_hint);

@@ -173,6 +173,7 @@ struct mbpe_ctx {
     uint32_t *LR = nullptr;               // xb + hdr_words + hdrb_words
     BatchState *bs = nullptr;
     uint32_t *xb0 = nullptr;              // begin: [bp 65,536][header]
+    uint32_t *pair_cells = nullptr;       // byte x byte cell block per pair of a batch (launch_pair_cells_fold), or NULL
     RankEdge *d_left = nullptr, *d_right = nullptr;   // composed neighbours (multi-GPU)
 
     // training
@@ -222,6 +223,8 @@ struct mbpe_ctx {
     // read back while its stream pass runs, so that exactly the cells the batch can touch are exchanged
     uint32_t *h_seq = nullptr;      // pinned, 16 words: [0..3] the multi-GPU copy, [8..13] launch_seq_info's
     uint32_t *d_seq_info = nullptr; // 8 words of device memory for launch_seq_info
+    int64_t opt_pair_cells = -1;    // one atomic per match with byte neighbours (mbpe_dev.h: launch_pair_cells_fold): -1 for
+                                    //   streams from 64 Mi slots on, 0 never, 1 always
     int64_t opt_lockstep = -1;      // small corpora: the host waits for every selection and enqueues only the kernels that
                                     //   sequence needs (-1: when the stream is short enough, 0 never, 1 always)
     hipEvent_t ev_sel = nullptr;
@@ -330,7 +333,7 @@ void free_training(mbpe_ctx *c) {
     tfree(c, c->offsets);
     tfree(c, c->tab.hslot); tfree(c, c->tab.ekey); tfree(c, c->tab.ecnt); tfree(c, c->tab.cells);
     tfree(c, c->tab.bmax); tfree(c, c->tab.smax);
-    tfree(c, c->bp); tfree(c, c->ctl); tfree(c, c->best); tfree(c, c->xb); tfree(c, c->xb0);
+    tfree(c, c->bp); tfree(c, c->ctl); tfree(c, c->best); tfree(c, c->xb); tfree(c, c->xb0); tfree(c, c->pair_cells);
     tfree(c, c->d_left); tfree(c, c->d_right); tfree(c, c->bs); tfree(c, c->sel); tfree(c, c->seq_flags); tfree(c, c->run_in);
     tfree(c, c->first_state);
     tfree(c, c->xf);
@@ -553,6 +556,7 @@ int mbpe_set_option(mbpe_ctx *c, const char *name, int64_t value) {
     else if (n == "sel_cap") c->opt_sel_cap = std::min<int64_t>(std::max<int64_t>(64, value), kSelCap);
     else if (n == "byte_table") c->opt_byte_table = value != 0;
     else if (n == "lockstep") c->opt_lockstep = value < 0 ? -1 : value != 0;
+    else if (n == "pair_cells") c->opt_pair_cells = value < 0 ? -1 : value != 0;      // (read by the next mbpe_train_begin)
     else if (n == "wide_from") c->opt_wide_from = value < 0 ? -1 : value;      // (read by the next mbpe_train_begin)
     else if (n == "pc_repeat") c->opt_pc_repeat = std::min<int64_t>(std::max<int64_t>(1, value), 1000);
     else { mbpe_host::set_last_error("unknown option " + n); return MBPE_ERR_ARG; }
@@ -828,6 +832,11 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
     HIPCHK(tmalloc(c, &c->xb0, xb0_words * 4));
     HIPCHK(hipMemsetAsync(c->xb, 0, xb_words * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->xb0, 0, xb0_words * 4, c->stream));
+    if (c->opt_pair_cells > 0 || (c->opt_pair_cells < 0 && c->n_slots >= (64ull << 20))) {
+        const size_t cells = (size_t)c->max_batch_eff * 65536u;
+        HIPCHK(tmalloc(c, &c->pair_cells, cells * 4));
+        HIPCHK(hipMemsetAsync(c->pair_cells, 0, cells * 4, c->stream));
+    }
     c->hdr_m = c->xb + c->hdr_words;
     c->hdr_adj = c->hdr_m + kBatchMax;
     c->LR = c->xb + c->hdr_words + c->hdrb_words;
@@ -1079,11 +1088,12 @@ static int seq_lockstep(mbpe_ctx *c, int ev_slot, bool *nothing_left) {
     if (batch_n == 1) {
     } else if (fused) {
         launch_fused_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->bs, c->hdr_adj, c->LR,
-                           c->ctl, nullptr, nullptr, endbit, c->n_cus, c->hdr_m, c->run_in, (int)hot, only);
+                           c->ctl, nullptr, nullptr, endbit, c->n_cus, c->hdr_m, c->run_in, (int)hot, only, c->pair_cells);
     } else {
         launch_scan_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
-                          c->ctl, nullptr, nullptr, endbit, c->n_cus, c->run_in, (int)hot, only);
+                          c->ctl, nullptr, nullptr, endbit, c->n_cus, c->run_in, (int)hot, only, c->pair_cells);
     }
+    if (batch_n >= 2) launch_pair_cells_fold(c->stream, c->pair_cells, c->LR, c->ctl, batch_n);
     if (ev_slot >= 0) { (void)hipEventRecord(c->kev_f[2 * ev_slot + 1], c->stream); (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream); }
     c->k_upper = std::min<uint32_t>(c->n_target, c->h_seq[8] + batch_n);
     const uint32_t id_upper = 256 + c->k_upper;
@@ -1120,10 +1130,14 @@ static int seq_stage_a(mbpe_ctx *c, int ev_slot) {       // up to the delta exch
     launch_merge(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->best, 0, endbit, c->LR, c->ctl,
                  multi ? c->xb : &c->ctl->m, le, re, c->n_cus, 1, c->offsets + c->n_tiles, c->run_in, c->bs, c->hot_possible);
     launch_scan_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->n_tiles, c->chg, c->bs, c->hdr_m, c->hdr_adj, c->LR,
-                      c->ctl, le, re, endbit, c->n_cus, c->run_in, c->hot_possible);
+                      c->ctl, le, re, endbit, c->n_cus, c->run_in, c->hot_possible, -1, c->pair_cells);
     if (ev_slot >= 0) (void)hipEventRecord(c->kev_f[2 * ev_slot], c->stream);
     launch_fused_batch(c->stream, c->tok[0], c->tok[1], c->sums, c->side, c->n_tiles, c->chg, c->bs, c->hdr_adj, c->LR,
-                       c->ctl, le, re, endbit, c->n_cus, c->hdr_m, c->run_in, c->hot_possible);
+                       c->ctl, le, re, endbit, c->n_cus, c->hdr_m, c->run_in, c->hot_possible, -1, c->pair_cells);
+    // (the cell blocks become L / R rows before anything reads the rows: the exchange of several ranks, validation, apply.
+    //  Inside the events: the fold is part of what the pass costs)
+    launch_pair_cells_fold(c->stream, c->pair_cells, c->LR, c->ctl,
+                           c->merges_per_seq > 0 && c->merges_per_seq < 128.0 ? 256u : c->max_batch_eff);
     if (ev_slot >= 0) {
         (void)hipEventRecord(c->kev_f[2 * ev_slot + 1], c->stream);
         (void)hipEventRecord(c->kev[2 * ev_slot + 1], c->stream);
@@ -1582,7 +1596,7 @@ static int wide_convert(mbpe_ctx *c) {
     c->wide_active = true;
     // the 16-bit stream and table are done with (their merges stay in best[])
     tfree(c, c->tok[0]); tfree(c, c->tok[1]); tfree(c, c->sums); tfree(c, c->side); tfree(c, c->chg); tfree(c, c->tile_list);
-    tfree(c, c->offsets); tfree(c, c->run_in); tfree(c, c->xb);
+    tfree(c, c->offsets); tfree(c, c->run_in); tfree(c, c->xb); tfree(c, c->pair_cells);
     tfree(c, c->tab.hslot); tfree(c, c->tab.ekey); tfree(c, c->tab.ecnt); tfree(c, c->tab.bmax); tfree(c, c->tab.smax);
     c->LR = nullptr;
     pool_trim(c);

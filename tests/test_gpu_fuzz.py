@@ -15,7 +15,7 @@ from mbpe import check
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 4096, "fused_min": 24,
-            "dense_table": -1, "threshold_select": 1, "sel_cap": 8192, "chunk_barrier": -1, "lockstep": -1}
+            "dense_table": -1, "threshold_select": 1, "sel_cap": 8192, "chunk_barrier": -1, "lockstep": -1, "pair_cells": -1}
 
 
 def _case(rng, text):
@@ -49,7 +49,10 @@ def _case(rng, text):
             "chunk_barrier": int(rng.choice([-1, 1])),        # (chunk ends as barrier slots: tests/test_gpu_barrier.py)
             # the host waits for every selection and enqueues only that sequence's kernels (the default at these sizes), or
             # enqueues whole groups of sequences with every kernel variant (what large corpora get)
-            "lockstep": int(rng.choice([0, 1]))}
+            "lockstep": int(rng.choice([0, 1])),
+            # matches between raw bytes counted with one atomic on the pair's byte x byte cell block (what streams from
+            # 64 Mi slots on get) or with two on its L and R rows
+            "pair_cells": int(rng.choice([0, 1]))}
     return data, off, vocab, opts
 
 

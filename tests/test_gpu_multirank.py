@@ -31,11 +31,14 @@ EXTRA_OPTS = {}       # further options set on every rank's context
 
 @pytest.fixture(params=[2, 1000], autouse=True, ids=["fused", "scan_rewrite"])
 def _both_batch_paths(request):
-    """Every test runs with the fused pass forced on (k_fused_batch) and forced off."""
-    global FUSED_MIN
+    """Every test runs with the fused pass forced on (k_fused_batch; matches between raw bytes counted in the pairs' cell
+    blocks, folded into the L / R rows before the exchange) and forced off (rows only)."""
+    global FUSED_MIN, EXTRA_OPTS
     FUSED_MIN = request.param
+    EXTRA_OPTS = dict(EXTRA_OPTS, pair_cells=1 if request.param == 2 else 0)
     yield
     FUSED_MIN = 24
+    EXTRA_OPTS = {k: v for k, v in EXTRA_OPTS.items() if k != "pair_cells"}
 
 
 EXCHANGES = []        # (u32 words, merges committed before) of every exchange of the run in progress

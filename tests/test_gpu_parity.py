@@ -261,7 +261,7 @@ def test_train_tiny_inputs(tr, data, vocab):
 
 DEFAULTS = {"compact_den": 16, "batch": 16, "multi_merge": 1, "max_batch": 4096, "fused_min": 24, "hier_argmax": -1,
             "dense_table": -1, "threshold_select": 1, "sel_cap": 8192, "chunk_barrier": -1, "first_batches": 0, "byte_table": 1,
-            "wide_from": -1, "lockstep": -1}
+            "wide_from": -1, "lockstep": -1, "pair_cells": -1}
 
 
 def _defaults(tr):
@@ -275,6 +275,9 @@ def _step_parity(tr, data, off, vocab, stride=1, **opts):
     # (small corpora run in lockstep by default -- the host waits for every selection and enqueues only that sequence's
     #  kernels; large ones enqueue whole groups with every kernel variant: the cases alternate between the two)
     opts.setdefault("lockstep", (len(data) + vocab) & 1)
+    # (likewise the count of a match between two raw bytes: one atomic on the pair's cell block -- large streams -- or two
+    #  on its L and R rows)
+    opts.setdefault("pair_cells", ((len(data) + vocab) >> 1) & 1)
     for k, v in opts.items():
         tr.set_option(k, v)
     try:
