@@ -3223,7 +3223,7 @@ __global__ __launch_bounds__(kLutThreads) void k_scan_batch(const uint16_t *tok0
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
     const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(LR, 0, 0xFFFFFFFCu, 0x00020000);
     // (the pairs' byte x byte cell blocks: see k_pair_cells_fold; not with the delta cache of frequent pairs)
-    const bool use_t = T != nullptr && !HOT;
+    const bool use_t = T != nullptr && !HOT && ctl->cells_on != 0u && n_keys >= ctl->cells_min;
     const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(T ? T : LR, 0, T ? 0xFFFFFFFCu : 0u, 0x00020000);
     TileIn t0 = tile_issue(tok, sums_rsrc, tile);
     TileIn t1 = tile_issue(tok, sums_rsrc, clamp_tile((uint64_t)tile + n_waves));
@@ -3721,7 +3721,7 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<TileSum *>(sin), 0, n_tiles * 16u, 0x00020000);
     const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(LR, 0, 0xFFFFFFFCu, 0x00020000);
     // (the pairs' byte x byte cell blocks: see k_pair_cells_fold; not with the delta cache of frequent pairs)
-    const bool use_t = T != nullptr && !HOT;
+    const bool use_t = T != nullptr && !HOT && ctl->cells_on != 0u && n_keys >= ctl->cells_min;
     const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(T ? T : LR, 0, T ? 0xFFFFFFFCu : 0u, 0x00020000);
     const uint32_t adj_pitch = rfl(ctl->adj_pitch);
     // kDepth tiles are in flight behind the one being worked on (5 registers each)
@@ -3881,8 +3881,9 @@ __global__ __launch_bounds__(kLutThreads, MBPE_FUSED_WAVES * 256 / kLutThreads) 
 __global__ __launch_bounds__(256) void k_pair_cells_fold(uint32_t *__restrict__ T, uint32_t *__restrict__ LR, const DevCtl *ctl) {
     __shared__ uint32_t rows[256];
     const uint32_t n = ctl->batch_n;
-    if (n < 2) return;
+    if (n < ctl->cells_min || !ctl->cells_on) return;          // (the pass did not use the blocks: see k_fused_batch)
     const uint32_t pitch = lr_pitch(256u + ctl->k_done);
+    uint32_t hits = 0;
     const uint32_t t = threadIdx.x;
     for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
         uint32_t *tj = T + (size_t)j * 65536u;
@@ -3901,8 +3902,11 @@ __global__ __launch_bounds__(256) void k_pair_cells_fold(uint32_t *__restrict__ 
         __syncthreads();
         if (col) LR[lr_idx(pitch, t, j, 1u)] += col;             // R_j[y = t]
         if (rows[t]) LR[lr_idx(pitch, t, j, 0u)] += rows[t];     // L_j[x = t]
+        hits += col;
         __syncthreads();
     }
+    hits = wave_sum(hits);
+    if (lane_id() == 0 && hits) atomicAdd(const_cast<uint32_t *>(&ctl->cell_hits), hits);
 }
 
 // Validation (after the all-reduce in a multi-GPU run).  Merge j creates the pairs (x, X_j) with
@@ -4533,6 +4537,7 @@ __global__ __launch_bounds__(kLutThreads) void k_rewrite_marked(uint16_t *tok0, 
 __global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag, const BatchState *bs) {
     if (blockIdx.x || threadIdx.x) return;
     const uint32_t bs_skip_n = bs->skip_n;
+    const uint32_t rm_seq = ctl->batch_n >= 2 ? ctl->rm : 0u;      // tokens this sequence removed = its matches (this rank)
     if (fused_flag) *fused_flag = ctl->fused && ctl->batch_n >= 2 ? 1u : 0u;
     if (ctl->batch_n >= 2) {       // (a single-pair batch was accounted by k_apply)
         const uint32_t rm = ctl->rm;
@@ -4558,6 +4563,12 @@ __global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag, const BatchState
         ctl->skip_penalty /= 2u;
     }
     ctl->skip_failed = 0;
+    // the pairs' cell blocks: once fewer than a third of a large batch's matches lay between two raw bytes the stream is
+    // past the stage where that pays (the share only falls as tokens replace bytes)
+    if (ctl->cells_on && ctl->cells_min >= kCellsMinBatch && ctl->batch_n >= ctl->cells_min &&
+        ctl->cell_hits * 3ull < (unsigned long long)rm_seq)
+        ctl->cells_on = 0;
+    ctl->cell_hits = 0;
     if (ctl->fused && ctl->batch_n >= 2) {
         ctl->n_fused += 1;
         if (ctl->commit_n == ctl->batch_n) ctl->cur ^= 1u;   // the fused pass's output becomes the stream

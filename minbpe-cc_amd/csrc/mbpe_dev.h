@@ -145,6 +145,12 @@ struct DevCtl {
     uint32_t first_tie;         // the selection took ONE pair whose count is shared: k_first_* pick the one that comes first
     uint32_t marks_all;         // the fused pass of this sequence wrote EVERY tile's summary to the side array and set no
                                 //   tile marks (its tiles nearly all change): "every tile is marked"
+    uint32_t cells_on;          // (host sets 1 at begin when the pairs' cell blocks exist) matches between two raw bytes are
+                                //   counted in the pair's byte x byte cell block (k_pair_cells_fold); k_seq_finish clears it for
+                                //   good once fewer than a third of a large batch's matches were of that kind
+    uint32_t cell_hits;         // matches counted that way in the sequence under way (k_pair_cells_fold)
+    uint32_t cells_min;         // (host, at begin) batches of at least this many pairs use the blocks (kCellsMinBatch; 2 when the
+                                //   "pair_cells" option forces them on: tests)
     uint32_t adj_pitch;         // (host, at begin) row pitch of the ADJ block: the largest batch this training can select
                                 //   ("max_batch" rounded up to 64), so that the block -- and what several GPUs exchange of
                                 //   it -- is as small as the batches allow
@@ -185,6 +191,9 @@ constexpr uint32_t kTTSlots = 256;
 #define MBPE_SKIP_MAX 32
 #endif
 constexpr int kSkipMax = MBPE_SKIP_MAX;
+// batches of at least this many pairs count matches between raw bytes in the pairs' cell blocks (smaller ones are not bound
+// by their atomics: there the extra tests cost more than the saved atomic -- same box, 976-pair pass: 8.1 -> 8.5 ms)
+constexpr uint32_t kCellsMinBatch = 512;
 constexpr uint32_t kNoTT = 0xFFFFFFFFu;
 struct BatchState {
     uint32_t key[kBatchMax];      // (first << 16) | second

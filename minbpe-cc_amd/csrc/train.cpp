@@ -865,6 +865,8 @@ static int begin_local(mbpe_ctx *c, uint32_t vocab_size) {
         init.n_ranks = (uint32_t)std::max(1, c->n_ranks);
         init.first_mode = c->opt_first ? 1u : 0u;
         init.adj_pitch = c->adj_pitch;
+        init.cells_on = c->pair_cells ? 1u : 0u;
+        init.cells_min = c->opt_pair_cells > 0 ? 2u : kCellsMinBatch;      // (forced on: every batch, and for the whole run)
         c->h_ctl = init;
         HIPCHK(hipMemcpyAsync(c->ctl, &c->h_ctl, sizeof(DevCtl), hipMemcpyHostToDevice, c->stream));
     }
