@@ -4563,10 +4563,10 @@ __global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag, const BatchState
         ctl->skip_penalty /= 2u;
     }
     ctl->skip_failed = 0;
-    // the pairs' cell blocks: once fewer than a third of a large batch's matches lay between two raw bytes the stream is
-    // past the stage where that pays (the share only falls as tokens replace bytes)
+    // the pairs' cell blocks: once fewer than half of a large batch's matches lay between two raw bytes the stream is
+    // past the stage where that pays (at a third the pass is already 2-8 % slower with the blocks than without) (the share only falls as tokens replace bytes)
     if (ctl->cells_on && ctl->cells_min >= kCellsMinBatch && ctl->batch_n >= ctl->cells_min &&
-        ctl->cell_hits * 3ull < (unsigned long long)rm_seq)
+        ctl->cell_hits * 2ull < (unsigned long long)rm_seq)
         ctl->cells_on = 0;
     ctl->cell_hits = 0;
     if (ctl->fused && ctl->batch_n >= 2) {

@@ -147,7 +147,7 @@ struct DevCtl {
                                 //   tile marks (its tiles nearly all change): "every tile is marked"
     uint32_t cells_on;          // (host sets 1 at begin when the pairs' cell blocks exist) matches between two raw bytes are
                                 //   counted in the pair's byte x byte cell block (k_pair_cells_fold); k_seq_finish clears it for
-                                //   good once fewer than a third of a large batch's matches were of that kind
+                                //   good once fewer than half of a large batch's matches were of that kind
     uint32_t cell_hits;         // matches counted that way in the sequence under way (k_pair_cells_fold)
     uint32_t cells_min;         // (host, at begin) batches of at least this many pairs use the blocks (kCellsMinBatch; 2 when the
                                 //   "pair_cells" option forces them on: tests)
