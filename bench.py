@@ -144,15 +144,17 @@ def cpu_baseline(data, merges, what):
 #                    delta_ps_per_match = (shipped - all but the count deltas) / matches of a pass
 # floor_model.floor_ms is the streaming floor; model_ms = "all but the count deltas" scaled to the pass's tiles + the
 # count deltas of its matches, next to measured_ms.
-FLOOR_FILE = os.path.join("profiles", "r03_fused_floor.json")
+FLOOR_FILE = os.path.join("profiles", "r04_fused_floor.json")
 FUSED_LIMITER = ("issue and the count-delta atomics, additively: timing-only builds of the kernel on the same passes "
-                 "(floor_model.ladder_ms from profiles/r03_fused_floor.json; tools/fused_diag.py) copy the stream in ~3.5 ms, "
-                 "hide the nine lookups per lane under that, take 5-6 ms with everything but the two count-delta atomics per "
-                 "match and 8 ms (743-pair passes, 4.9e7 matches) to 20 ms (passes of 2,100-4,096 pairs, 1.9e8 matches) as shipped: "
-                 "56-70 ps per match that no other work of the wave overlaps (four waves per SIMD: the lookup table fills "
-                 "the LDS; six waves hide half of it, XCD-private counters nothing: DESIGN.md section 8).  The vector "
-                 "instructions (~430-460 per 512-slot tile, SIMDs ~60 % busy) went down with the prefix-form tiles of "
-                 "round 3 (no chains over holes), the time by 3-7 % (DESIGN.md section 4)")
+                 "(floor_model.ladder_ms from profiles/r04_fused_floor.json; tools/fused_diag.py) copy the stream in ~3.5 ms, "
+                 "hide the nine lookups per lane under that, take ~6.4 ms with everything but the count-delta atomics and 15 ms "
+                 "as shipped on passes of 2,100-4,096 pairs (1.9e8 matches): 44 ps per match that no other work of the wave "
+                 "overlaps (four waves per SIMD: the lookup table fills the LDS).  Round 4 took a quarter of those atomics away "
+                 "(a match between two raw bytes: one atomic on its pair's byte x byte cell block instead of two on the L / R "
+                 "rows, k_pair_cells_fold behind the pass: 70 -> 44 ps per match) and made the stream's loads and stores "
+                 "non-temporal (+3 %); what remains is the memory side's rate for scattered atomics (~30 G/s) in the passes of "
+                 "thousands of pairs and ~1.5 ms of vector-issue-bound work per pass everywhere else (DESIGN.md section 4, "
+                 "profiles/HISTORY.md)")
 
 
 def published_workload(device, with_cpu):

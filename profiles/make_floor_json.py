@@ -54,5 +54,5 @@ print(json.dumps({
     "clock_GHz": clock,
     "valu_busy_frac": c["SQ_INSTS_VALU"] * 4.0 / (c["SQ_BUSY_CYCLES"] / 32.0 * 1024.0),
     "simds": 1024,
-    "sources": "tools/fused_diag.py (MBPE_FUSED_DIAG=4) + rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace of one bench.py run, collected by profiles/collect_r03.sh",
+    "sources": "tools/fused_diag.py (MBPE_FUSED_DIAG=4) + rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace of one bench.py run, collected by profiles/collect_r0N.sh",
 }, indent=1))
