@@ -529,13 +529,16 @@ def main():
                 "floor_model": floor_model,
             },
             "roofline_pair_count": {
-                "kernel": "k_pair_count_u8",
+                "kernel": "k_pair_count_u8_fast",
                 "bound": "hbm",
+                "bound_is": "the LDS: one atomic per pair into a 128-KiB histogram per CU; 2^32 random LDS atomics alone take "
+                            "0.81 ms on this chip (tools/lds_atomic_floor.hip: 0.66 of the HBM peak), the HBM roof is the "
+                            "reporting convention",
                 "achieved": scan_gbs,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": scan_gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("k_pair_count_u8", args.config, total_bytes, vocab, world),
+                "traffic": pmc_traffic("k_pair_count_u8_fast", args.config, total_bytes, vocab, world),
                 "algorithmic_bytes_per_launch": hi - lo,
                 "avg_launch_ms": scan_ms_avg,
                 "avg_launch_ms_is": "mean kernel duration of launches 26-55 of 55 (three groups of ten launches back to back), "
