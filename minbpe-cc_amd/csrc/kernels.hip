@@ -3674,6 +3674,9 @@ __device__ __forceinline__ uint4 fused_tile_pf(const uint4 q_orig, const uint32_
 #ifndef MBPE_SKIP_PENALTY0
 #define MBPE_SKIP_PENALTY0 2
 #endif
+#ifndef MBPE_SKIP_PENALTY_MAX
+#define MBPE_SKIP_PENALTY_MAX 256
+#endif
 #ifndef MBPE_FUSED_WAVES
 #define MBPE_FUSED_WAVES 4
 #endif
@@ -4556,7 +4559,8 @@ __global__ void k_seq_finish(DevCtl *ctl, uint32_t *fused_flag, const BatchState
     // passing over dependent candidates: back off after a failure, recover after successes
     if (ctl->skip_off) ctl->skip_off -= 1;
     if (ctl->batch_n >= 2 && ctl->skip_failed) {
-        const uint32_t pen = ctl->skip_penalty ? (ctl->skip_penalty * 2u > 256u ? 256u : ctl->skip_penalty * 2u) : (uint32_t)MBPE_SKIP_PENALTY0;
+        const uint32_t pen = ctl->skip_penalty ? (ctl->skip_penalty * 2u > (uint32_t)MBPE_SKIP_PENALTY_MAX ? (uint32_t)MBPE_SKIP_PENALTY_MAX : ctl->skip_penalty * 2u)
+                                               : (uint32_t)MBPE_SKIP_PENALTY0;
         ctl->skip_penalty = pen;
         ctl->skip_off = pen;
     } else if (ctl->batch_n >= 2 && bs_skip_n > 0 && ctl->skip_penalty) {

@@ -484,6 +484,34 @@ def test_batched_parity_sparse_stream(tr, fused_min):
     _step_parity(tr, data, None, 256 + 200, stride=64, compact_den=0, fused_min=fused_min)
 
 
+def test_abandoned_fused_pass_over_empty_tiles(tr):
+    """A fused pass that validation abandons is redone by k_rewrite_marked over EVERY tile -- empty ones included.  A run
+    of 64 tiles of one byte halves with every merge of its (t,t) pair; without compaction the tenth merge (64 tokens, one
+    per tile: 63 overlapping pairs) leaves half of those tiles without a live token, and the text behind the run keeps
+    producing batches that validation cuts."""
+    text = read_data("shakespeare.txt")[3000:27000]
+    data = np.frombuffer(b"a" * (512 * 64) + text, dtype=np.uint8)
+    vocab = 256 + 700
+    want_m, want_c = O.train(data, vocab)
+    k_empty = next(k for k in range(len(want_c)) if want_c[k] == 63 and want_m[k][0] == want_m[k][1] and want_m[k][0] >= 256)
+    for k, v in {"compact_den": 0, "fused_min": 2, "lockstep": 0}.items():
+        tr.set_option(k, v)
+    try:
+        tr.load_corpus(data)
+        tr.train_begin(vocab)
+        assert tr.train_steps(k_empty + 1) == k_empty + 1
+        before = tr.stats()
+        assert before["n_compactions"] == 0 and before["n_live"] <= len(text) + 32      # (32 tokens of the run are left)
+        assert tr.train_steps(vocab - 256 - (k_empty + 1)) == vocab - 256 - (k_empty + 1)
+        after = tr.stats()
+        m, c = tr.train_result()
+    finally:
+        _defaults(tr)
+    assert after["n_fused_dropped"] > before["n_fused_dropped"], (before["n_fused_dropped"], after["n_fused_dropped"])
+    assert after["n_compactions"] == 0
+    assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
 def test_batched_vs_single_merge_mode(tr):
     data = O.splitmix64_bytes(77, 1 << 19)
     want_m, want_c = O.train(data, 256 + 400)
