@@ -86,3 +86,48 @@ def test_fuzz_against_oracle(seed):
                    {k: v for k, v in st.table_dict().items() if v}, tag
             assert check.tiles_in_prefix_form(tr, torch, torch.device("cuda", 0)), tag
             st.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MBPE_FUZZ_SEEDS", "4"))))
+def test_fuzz_first_mode_and_wide_handover(seed):
+    """The same random cases through the two other loops of the library: the `first` tie-break (one merge per pass, ties by
+    stream position; the oracle rebuilds its insertion-ordered table before every merge as Tokenizer.h:581-585 does) and
+    the 32-bit continuation, handed over to after a random number of merges ("wide_from")."""
+    text = read_data("shakespeare.txt")
+    with mbpe.Trainer(0) as tr:
+        for case in range(30):
+            rng = np.random.default_rng(9000 + seed * 1000 + case)
+            data, off, vocab, opts = _case(rng, text)
+            data = data[:20000]                               # (the first-mode oracle recounts per merge)
+            if off is not None:
+                off = np.concatenate([off[off < len(data)], [len(data)]]).astype(np.uint64)
+                off = np.unique(off)
+                if off[0] != 0:
+                    off = np.concatenate([[0], off]).astype(np.uint64)
+            vocab = min(vocab, 256 + 120)
+            for k, v in {**DEFAULTS, **opts}.items():
+                tr.set_option(k, v)
+            tag = (seed, case, len(data), vocab, off is not None, opts)
+            # first
+            want_m, want_c = O.train(data, vocab, off, mode=O.FIRST)
+            m, c, _ = tr.train(data, vocab, off, conflict_resolution=0)
+            assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist(), ("first",) + tag
+            # lexical, 32-bit tokens from merge `wide_from` on
+            wf = int(rng.integers(0, max(vocab - 256, 1) + 1))
+            tr.set_option("wide_from", wf)
+            try:
+                want_m, want_c = O.train(data, vocab, off)
+                m, c, _ = tr.train_lexical(data, vocab, off)
+                assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist(), ("wide", wf) + tag
+                if len(want_m):
+                    st = O.State(data, off)
+                    for i, (a, b) in enumerate(want_m):
+                        st.merge(int(a), int(b), 256 + i)
+                    starts = np.array([0], dtype=np.int64) if off is None else off[:-1].astype(np.int64)
+                    if len(data) and not np.any(data[starts[starts < len(data)]] == 0):
+                        assert np.array_equal(tr.stream()[0], st.stream()[0]), ("wide", wf) + tag
+                    assert {k: v for k, v in tr.pairs_dict().items() if v} == \
+                           {k: v for k, v in st.table_dict().items() if v}, ("wide", wf) + tag
+                    st.close()
+            finally:
+                tr.set_option("wide_from", -1)
