@@ -827,7 +827,17 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t
     // ragged tail: pairs starting at byte 16*n_full - 1 .. n-2
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         uint64_t i = n_full * 16;
-        if (i > 0) --i;                      // the pair straddling into the tail
+        // The pair straddling into the tail, (16 n_full - 1, 16 n_full).  The generic loop counts the pairs INSIDE the
+        // full vectors and leaves it to this code; a fast iteration counts every pair that starts in its blocks, so when
+        // the fast iterations of the workgroup that holds the last vector reach n_full it has been counted already.
+        bool straddle_counted = false;
+        if (n_full > 0) {
+            const uint64_t vb = per * ((n_full - 1) / per);          // that workgroup's first vector
+            uint64_t f = (n_full - vb) / kIterVecs;
+            while (f > 0 && (vb + f * kIterVecs) * 16 + 4 > n) --f;
+            straddle_counted = f > 0 && vb + f * kIterVecs == n_full;
+        }
+        if (i > 0 && !straddle_counted) --i;
         if (n_full * 16 == n) i = n;         // no tail at all
         for (; i + 1 < n; ++i) atomicAdd(&bp[((uint32_t)text[i] << 8) | text[i + 1]], 1u);
     }

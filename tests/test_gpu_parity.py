@@ -52,6 +52,28 @@ def test_pair_count_sizes(tr, n):
     assert np.array_equal(tr.pair_count_u8(), O.pair_count_u8(data))
 
 
+def test_pair_count_lengths_around_block_edges(tr):
+    """Corpus lengths around the scan kernels' units -- 16-byte vectors, 2-KiB wave blocks, 32-KiB workgroup iterations -- with
+    0..20 bytes before and behind them: which loop counts the pair that straddles into the ragged tail depends on where the
+    whole iterations end (a length of k x 32 KiB + 4..15 bytes once had it counted twice)."""
+    rng = np.random.default_rng(5)
+    base = rng.integers(97, 101, size=1 << 21, dtype=np.uint8)
+    sizes = set()
+    for k in (1, 2, 3, 4, 8, 16, 17, 32, 33, 48, 64):
+        for unit in (2048, 16384, 32768):
+            for d in list(range(-20, 21)) + [2047, 2049, 4099]:
+                if 2 <= k * unit + d <= len(base):
+                    sizes.add(k * unit + d)
+    bad = []
+    for n in sorted(sizes):
+        data = base[:n]
+        tr.load_corpus(data)
+        want = np.bincount((data[:-1].astype(np.uint32) << 8) | data[1:], minlength=65536).astype(np.uint32)
+        if not np.array_equal(tr.pair_count_u8(), want):
+            bad.append(n)
+    assert not bad, bad[:20]
+
+
 def test_pair_count_random_1mib(tr):
     data = O.splitmix64_bytes(42, 1 << 20)
     tr.load_corpus(data)
