@@ -131,3 +131,55 @@ def test_fuzz_first_mode_and_wide_handover(seed):
                     st.close()
             finally:
                 tr.set_option("wide_from", -1)
+
+
+def _medium_case(rng, text):
+    """1-6 MiB: thousands of tiles, every workgroup of the pair-count scan busy, compactions, selection retries
+    (the oracle needs 5-15 s per case: MBPE_FUZZ_MEDIUM sets the number of cases)."""
+    kind = int(rng.integers(0, 4))
+    n = int(rng.integers(1 << 20, 6 << 20))
+    if kind == 0:        # small alphabets: thousands of tied counts
+        data = rng.integers(0, int(rng.choice([3, 7, 20, 256])), size=n, dtype=np.uint8)
+    elif kind == 1:      # a text slice repeated, with a random prefix so that copies do not line up with tiles
+        s = int(rng.integers(0, len(text) - 300000))
+        l = int(rng.integers(1000, 300000))
+        data = np.frombuffer((text[s:s + l] * (n // l + 1))[:n], dtype=np.uint8).copy()
+    elif kind == 2:      # runs
+        vals = rng.integers(97, 103, size=max(n // 20, 1), dtype=np.uint8)
+        data = np.repeat(vals, rng.integers(1, 40, size=len(vals)))[:n]
+    else:                # the benchmark's generator
+        data = O.splitmix64_bytes(int(rng.integers(1, 1 << 30)), n)
+    data = np.ascontiguousarray(data)
+    off = None
+    if rng.integers(0, 3) == 0:
+        cuts = np.unique(rng.integers(1, len(data), size=len(data) // int(rng.integers(4, 4000))))
+        off = np.concatenate([[0], cuts, [len(data)]]).astype(np.uint64)
+    vocab = 256 + int(rng.integers(50, 700))
+    opts = {"fused_min": int(rng.choice([2, 24, 24, 1000])), "dense_table": int(rng.choice([0, 1])),
+            "compact_den": int(rng.choice([2, 16, 16])), "batch": int(rng.choice([1, 16, 16])),
+            "max_batch": int(rng.choice([64, 4096, 4096])), "chunk_barrier": int(rng.choice([-1, 1])),
+            "lockstep": int(rng.choice([0, 1, -1])), "pair_cells": int(rng.choice([0, 1]))}
+    return data, off, vocab, opts
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MBPE_FUZZ_MEDIUM", "4"))))
+def test_fuzz_medium_sizes_against_oracle(seed):
+    text = read_data("shakespeare.txt")
+    rng = np.random.default_rng(40000 + seed)
+    data, off, vocab, opts = _medium_case(rng, text)
+    want_m, want_c = O.train(data, vocab, off)
+    with mbpe.Trainer(0) as tr:
+        for k, v in {**DEFAULTS, **opts}.items():
+            tr.set_option(k, v)
+        m, c, _ = tr.train_lexical(data, vocab, off)
+        tag = (seed, len(data), vocab, off is not None, opts)
+        assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist(), tag
+        if len(want_m):
+            st = O.State(data, off)
+            for i, (a, b) in enumerate(want_m):
+                st.merge(int(a), int(b), 256 + i)
+            assert {k: v for k, v in tr.pairs_dict().items() if v} == {k: v for k, v in st.table_dict().items() if v}, tag
+            starts = np.array([0], dtype=np.int64) if off is None else off[:-1].astype(np.int64)
+            if not np.any(data[starts] == 0):
+                assert np.array_equal(tr.stream()[0], st.stream()[0]), tag
+            st.close()

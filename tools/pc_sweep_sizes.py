@@ -23,6 +23,19 @@ with mbpe.Trainer(0) as tr:
         if not np.array_equal(got, want):
             idx = np.nonzero(got != want)[0]
             bad.append((n, [(int(i) >> 8, int(i) & 255, int(got[i]), int(want[i])) for i in idx[:4]]))
+# a few large ones: every workgroup busy, the last workgroups' ranges short or empty
+big = rng.integers(97, 101, size=(96 << 20) + 64, dtype=np.uint8)
+with mbpe.Trainer(0) as tr:
+    for n in [(8 << 20) + d for d in (-17, -1, 0, 3, 4, 9, 15, 16, 31)] + [(8 << 20) + 32768 * 7 + 5, (24 << 20) + 11, (33 << 20) + 32768 + 4,
+                                                                       (96 << 20) + 13, 256 * 32768 * 3 - 32768 + 6]:
+        data = big[:n]
+        tr.load_corpus(data)
+        got = tr.pair_count_u8()
+        want = np.bincount((data[:-1].astype(np.uint32) << 8) | data[1:], minlength=65536).astype(np.uint32)
+        sizes.add(n)
+        if not np.array_equal(got, want):
+            idx = np.nonzero(got != want)[0]
+            bad.append((n, [(int(i) >> 8, int(i) & 255, int(got[i]), int(want[i])) for i in idx[:4]]))
 print("sizes", len(sizes), "bad", len(bad))
 for b in bad[:40]:
     print(b)
