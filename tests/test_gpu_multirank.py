@@ -4,6 +4,7 @@ plays the collective (sum of the exchange buffers) through the external-transpor
 C-ABI.  Everything except the ncclAllReduce call itself is the production path.
 Results must equal the single-rank oracle on the whole corpus."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -230,12 +231,13 @@ def test_tie_heavy_text_three_ranks():
     _check(data, [len(data) // 3 + 5, 2 * len(data) // 3 - 7], 256 + 900)
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MBPE_FUZZ_SHARDED", "3"))))
 def test_fuzz_sharded(seed):
-    # random corpora (small alphabets, repeated blocks, runs), random cuts, 2-4 ranks
+    # random corpora (small alphabets, repeated blocks, runs), random cuts, 2-4 ranks; a third of them chunked (shards hold
+    # whole chunks), a quarter with the `first` tie-break, some long enough for the pair-count scan's whole iterations
     rng = np.random.default_rng(4200 + seed)
     for _ in range(6):
-        n = int(rng.integers(20, 30000))
+        n = int(rng.integers(20, 30000)) if rng.integers(0, 4) else int(rng.integers(30000, 150000))
         kind = int(rng.integers(0, 3))
         if kind == 0:
             data = rng.integers(97, 97 + int(rng.choice([2, 4, 26])), size=n, dtype=np.uint8)
@@ -246,8 +248,18 @@ def test_fuzz_sharded(seed):
             vals = rng.integers(97, 100, size=max(n // 20, 1), dtype=np.uint8)
             data = np.repeat(vals, rng.integers(1, 60, size=len(vals)))[:n]
         R = int(rng.integers(2, 5))
-        cuts = sorted(set(int(x) for x in rng.integers(1, len(data), size=R - 1)))
-        _check(data.tobytes(), cuts, 256 + int(rng.integers(5, 120)))
+        chunk_off = None
+        if rng.integers(0, 3) == 0 and len(data) > 8:
+            inner = np.unique(rng.integers(1, len(data), size=max(len(data) // int(rng.integers(2, 300)), R)))
+            chunk_off = np.concatenate([[0], inner, [len(data)]]).astype(np.uint64)
+            cuts = sorted(set(int(x) for x in rng.choice(inner, size=min(R - 1, len(inner)), replace=False)))
+        else:
+            cuts = sorted(set(int(x) for x in rng.integers(1, len(data), size=R - 1)))
+        vocab = 256 + int(rng.integers(5, 120))
+        if rng.integers(0, 4) == 0:
+            _check_first(data.tobytes(), cuts, min(vocab, 256 + 40), chunk_off)
+        else:
+            _check(data.tobytes(), cuts, vocab, chunk_off)
 
 
 def _check_first(data, cuts, vocab, chunk_off=None):
