@@ -2331,13 +2331,19 @@ __device__ __forceinline__ uint32_t lut_index_known(const BatchLut &lut, uint32_
 // the other buffer) or scan + rewrite of the marked tiles (reads once, then re-reads and rewrites
 // the tiles that hold a match).  The fused pass wins once a good part of the tiles hold a match:
 // many pairs, or few but frequent ones (text).  fused_min >= 1000 turns it off.
+__device__ __forceinline__ bool want_fused_sum(unsigned long long matches, uint32_t accepted, uint32_t fused_min,
+                                               unsigned long long n_live_all) {
+    if (accepted < 2 || fused_min >= 1000u) return false;
+    if (accepted >= fused_min) return true;
+    return matches * 2048ull >= n_live_all;        // about one tile in five holds a match
+}
 __device__ __forceinline__ bool want_fused(const BatchState *bs, uint32_t accepted, uint32_t fused_min,
                                            unsigned long long n_live_all) {
     if (accepted < 2 || fused_min >= 1000u) return false;
     if (accepted >= fused_min) return true;
     unsigned long long matches = 0;
     for (uint32_t i = 0; i < accepted; ++i) matches += bs->packed[i] >> 32;
-    return matches * 2048ull >= n_live_all;        // about one tile in five holds a match
+    return want_fused_sum(matches, accepted, fused_min, n_live_all);
 }
 
 __global__ __launch_bounds__(kHierThreads) void k_select_batch(PairTable t, DevCtl *ctl, BatchState *bs,
@@ -2834,6 +2840,9 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         // (a batch that goes through the hash table after all -- a single byte pair: no table at all -- is caught up with;
         //  nothing can drop out any more: every member behind a non-byte one was tracked when it was accepted)
         // the members' records, all lanes at once
+        // (and the sum of their counts for want_fused: one thread reading the records back from global memory cost a
+        //  round trip per pair on text, where batches stay below fused_min)
+        unsigned long long count_sum = 0;
         for (uint32_t i = tid; i < accepted; i += kWave) {
             const uint32_t at = acc_ci[i];
             const unsigned long long cand = sp[at];
@@ -2842,7 +2851,10 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
             bs->packed[i] = cand;
             bs->maxp[i] = 0;
             best[k0 + i] = cand;
+            count_sum += cand >> 32;
         }
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) count_sum += shfl_xor_u64(count_sum, d);
         // (candidates passed over behind the last member do not matter: nothing was chosen after them)
         if (tid == 0) {
             bs->skip_n = n_skip; bs->tt_n = n_tt; ctl->n_skipped += n_skip;
@@ -2852,8 +2864,7 @@ __global__ __launch_bounds__(kPickThreads) void k_sel_pick(DevCtl *ctl, BatchSta
         if (tid == 0) {
             ctl->batch_n = accepted;
             ctl->commit_n = accepted;
-            __threadfence_block();
-            ctl->fused = want_fused(bs, accepted, fused_min, ctl->n_live * n_ranks) ? 1u : 0u;
+            ctl->fused = want_fused_sum(count_sum, accepted, fused_min, ctl->n_live * n_ranks) ? 1u : 0u;
             ctl->n_batches += 1;
             ctl->sel_ok = 1;
             if (cut == 1u) ctl->cut_conflict += 1;
@@ -5030,7 +5041,8 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap, bool byte_table, int attempts) {
+                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap, bool byte_table, int attempts,
+                         int first_attempt, bool fallback) {
     const uint32_t fake_id = (endbit == kEndBit ? 0x7FFFu : 0xFFFFu) - 1u;      // see tt_rename
     // stand-in ids of (t,t) members are the kTTMax ids below the hole / end-bit mask: only while no token has them
     const uint32_t tt_max = 256u + n_target <= fake_id + 1u - (uint32_t)kTTMax ? (uint32_t)kTTMax : 1u;
@@ -5040,14 +5052,15 @@ void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs
         const int blocks = (n_cus > 0 ? n_cus : 256) * 4;
         // (attempts 1 and 2 only work after an overflowing or empty first gather; when they are needed and were not
         //  enqueued the bound-walking kernel below selects -- slower, never wrong)
-        for (int attempt = 0; attempt < (attempts < 1 ? 1 : attempts > 3 ? 3 : attempts); ++attempt) {
+        for (int attempt = first_attempt < 0 ? 0 : first_attempt; attempt < (attempts < 1 ? 1 : attempts > 3 ? 3 : attempts); ++attempt) {
             hipLaunchKernelGGL(k_sel_scan, dim3(blocks), dim3(256), 0, s, t, ctl, sel, n_target, sel_cap, attempt);
             hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(kPickThreads), 0, s, ctl, bs, sel, best, n_target, max_batch,
                                fused_min, (uint32_t)n_ranks, attempt, fake_id, sel_cap, tt_max, byte_table ? 1u : 0u);
         }
     }
-    hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch,
-                       fused_min, (uint32_t)n_ranks);
+    if (fallback)
+        hipLaunchKernelGGL(k_select_batch, dim3(1), dim3(kHierThreads), 0, s, t, ctl, bs, best, n_target, max_batch,
+                           fused_min, (uint32_t)n_ranks);
 }
 
 void launch_fused_batch(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const TileSum *sums, TileSum *side,
@@ -5210,6 +5223,8 @@ __global__ void k_seq_info(const DevCtl *ctl, const BatchState *bs, const unsign
     out[3] = tt;
     out[4] = dc_wanted(top, ctl->n_live * ctl->n_ranks) ? 1u : 0u;
     out[5] = ctl->k_limit;
+    out[6] = ctl->sel_ok;            // (the selection's first attempt chose the batch: the others are not needed)
+    out[7] = 0;
 }
 
 void launch_seq_info(hipStream_t s, const DevCtl *ctl, const BatchState *bs, const unsigned long long *best, uint32_t *out) {

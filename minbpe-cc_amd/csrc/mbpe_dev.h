@@ -330,7 +330,9 @@ void launch_patch_sums(hipStream_t s, const unsigned long long *best, TileSum *s
 // prefix), then k_select_batch (walks the argmax bounds one pair at a time) if that could not be used
 void launch_select_batch(hipStream_t s, PairTable t, DevCtl *ctl, BatchState *bs, SelList *sel,
                          unsigned long long *best, uint32_t n_target, uint32_t max_batch, uint32_t fused_min,
-                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap, bool byte_table, int attempts = 3);
+                         int n_cus, int n_ranks, uint32_t endbit, uint32_t sel_cap, bool byte_table, int attempts = 3,
+                         int first_attempt = 0 /* attempts first_attempt .. attempts - 1 */,
+                         bool fallback = true /* the bound-walking kernel behind them */);
 // (up to three gather + pick attempts are enqueued: when the first gather overflows its list -- many equal
 //  counts -- the second lists the block bounds to find a threshold and the third gathers with it.  `attempts` 1: only
 //  the first; the host enqueues the other two while selections have needed them lately)
@@ -360,7 +362,8 @@ void launch_rewrite_marked(hipStream_t s, uint16_t *tok0, uint16_t *tok1, const 
                            const uint32_t *run_in /* as for launch_merge: used when the batch has a (t,t) member */,
                            int only = -1);
 // what the selection decided, for a host that enqueues only the kernels a sequence needs: out[0] merges done, [1] pairs
-// in the batch, [2] fused pass, [3] a (t,t) pair among them, [4] frequent-pair instantiation, [5] merge limit
+// in the batch, [2] fused pass, [3] a (t,t) pair among them, [4] frequent-pair instantiation, [5] merge limit,
+// [6] the batch was chosen by a gather + pick attempt (0 after the first attempt alone: enqueue the others and the fallback)
 void launch_seq_info(hipStream_t s, const DevCtl *ctl, const BatchState *bs, const unsigned long long *best, uint32_t *out);
 // fused_flag (optional, 4 words): [0] = 1 when this sequence ran the fused pass, [1..2] = live tokens of the shard after
 // the sequence, [3] = merges it committed

@@ -221,7 +221,7 @@ struct mbpe_ctx {
     uint32_t max_batch_eff = kBatchMax, adj_pitch = kBatchMax;   // (set by mbpe_train_begin: see begin_local)
     // multi-GPU: what the selection of the sequence in flight decided (k_done, k_limit, batch_n, commit_n of DevCtl),
     // read back while its stream pass runs, so that exactly the cells the batch can touch are exchanged
-    uint32_t *h_seq = nullptr;      // pinned, 16 words: [0..3] the multi-GPU copy, [8..13] launch_seq_info's
+    uint32_t *h_seq = nullptr;      // pinned, 16 words: [0..3] the multi-GPU copy, [8..15] launch_seq_info's
     uint32_t *d_seq_info = nullptr; // 8 words of device memory for launch_seq_info
     int64_t opt_pair_cells = -1;    // one atomic per match with byte neighbours (mbpe_dev.h: launch_pair_cells_fold): -1 for
                                     //   streams from 64 Mi slots on, 0 never, 1 always
@@ -1063,14 +1063,24 @@ static inline bool use_lockstep(const mbpe_ctx *c) {
 static int seq_lockstep(mbpe_ctx *c, int ev_slot, bool *nothing_left) {
     const uint32_t endbit = endbit_of(c);
     *nothing_left = false;
-    launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best,
-                        c->n_target, std::min<uint32_t>((uint32_t)c->opt_max_batch, c->max_batch_eff), (uint32_t)c->opt_fused_min, c->n_cus,
-                        1, endbit, (uint32_t)c->opt_sel_cap, c->opt_byte_table, c->sel_attempts);
+    // The first gather + pick attempt alone; only when it did not choose the batch (a list that overflowed or came back
+    // empty, an unprimed threshold: a few times per training) the other two and the bound-walking kernel follow, behind one
+    // more wait -- five launches fewer for every other sequence.
+    const uint32_t mb = std::min<uint32_t>((uint32_t)c->opt_max_batch, c->max_batch_eff);
+    const bool stepwise = c->opt_threshold_select != 0;
+    launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->opt_threshold_select ? c->sel : nullptr, c->best, c->n_target, mb,
+                        (uint32_t)c->opt_fused_min, c->n_cus, 1, endbit, (uint32_t)c->opt_sel_cap, c->opt_byte_table,
+                        stepwise ? 1 : c->sel_attempts, 0, !stepwise);
     if (!c->d_seq_info) HIPCHK(hipMalloc(&c->d_seq_info, 32));
-    launch_seq_info(c->stream, c->ctl, c->bs, c->best, c->d_seq_info);
-    HIPCHK(hipMemcpyAsync(c->h_seq + 8, c->d_seq_info, 24, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipEventRecord(c->ev_sel, c->stream));
-    HIPCHK(hipEventSynchronize(c->ev_sel));
+    for (int round = 0;; ++round) {
+        launch_seq_info(c->stream, c->ctl, c->bs, c->best, c->d_seq_info);
+        HIPCHK(hipMemcpyAsync(c->h_seq + 8, c->d_seq_info, 32, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->ev_sel, c->stream));
+        HIPCHK(hipEventSynchronize(c->ev_sel));
+        if (!stepwise || round > 0 || c->h_seq[14] != 0) break;
+        launch_select_batch(c->stream, c->tab, c->ctl, c->bs, c->sel, c->best, c->n_target, mb, (uint32_t)c->opt_fused_min,
+                            c->n_cus, 1, endbit, (uint32_t)c->opt_sel_cap, c->opt_byte_table, 3, 1, true);
+    }
     const uint32_t batch_n = c->h_seq[9], fused = c->h_seq[10], tt = c->h_seq[11], hot = c->h_seq[12];
     if (ev_slot >= 0) { (void)hipEventRecord(c->kev[2 * ev_slot], c->stream); (void)hipEventRecord(c->kev_f[2 * ev_slot], c->stream); }
     if (batch_n == 0) {                        // the merge limit is reached (or the table is empty): nothing to enqueue

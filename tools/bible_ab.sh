@@ -6,5 +6,5 @@ python - <<PY
 import json
 d=json.loads(open('gpurun_out/r4_bab_$tag.json').read().strip().splitlines()[-1])
 b=d['batches']
-print('$tag', 'ms/training %.2f'%d['ms_per_step'], 'value %.0f'%d['value'], 'passes', b['n_batches'], 'skipped', b['n_skipped'], 'skip_cut', b['n_skip_cut'], 'drops', b['n_validation_drops'], 'fused dropped', b['n_fused_dropped'], 'ok', d.get('checks',{}).get('ok'))
+print('$tag', 'ms/training %.2f'%d['ms_per_step'], 'value %.0f'%d['value'], 'passes', b['n_batches'], 'skipped', b['n_skipped'], 'skip_cut', b['n_skip_cut'], 'drops', b['n_validation_drops'], 'fused dropped', b['n_fused_dropped'], 'ok', (d.get('checks') or {}).get('ok'))
 PY
