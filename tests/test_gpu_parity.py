@@ -72,6 +72,17 @@ def test_pair_count_lengths_around_block_edges(tr):
         if not np.array_equal(tr.pair_count_u8(), want):
             bad.append(n)
     assert not bad, bad[:20]
+    # the same lengths cut into chunks (the masked scan): a pair whose first byte ends a chunk does not count
+    for n in sorted(sizes)[::7]:
+        data = base[:n]
+        off = _random_chunks(rng, n, int(rng.integers(2, 3000)))
+        tr.load_corpus(data, off)
+        keep = np.ones(n - 1, dtype=bool)
+        keep[off[1:-1].astype(np.int64) - 1] = False
+        want = np.bincount(((data[:-1].astype(np.uint32) << 8) | data[1:])[keep], minlength=65536).astype(np.uint32)
+        if not np.array_equal(tr.pair_count_u8(), want):
+            bad.append(("chunked", n))
+    assert not bad, bad[:20]
 
 
 def test_pair_count_random_1mib(tr):
