@@ -764,6 +764,11 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t
 
     unsigned long long resid = 0;          // decoded sum of the counters (uniform)
     uint32_t seg_iters = kPcSeg0;
+    // The pair that straddles from the last full vector into the ragged tail, (16 n_full - 1, 16 n_full): a fast iteration
+    // counts every pair that starts in its blocks -- this one too, when the workgroup's fast iterations end at n_full and
+    // the segment that holds the last of them stood; the generic loops (the remainder below, the recount of a void
+    // segment) count the pairs INSIDE the full vectors and leave it to the tail code at the end of the kernel.
+    bool straddle_counted = false;         // uniform
     for (uint32_t seg = 0; seg < F;) {
         const uint32_t seg_end = seg + seg_iters < F ? seg + seg_iters : F;
         if (resid) {                       // something to lose: snapshot
@@ -786,6 +791,7 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t
             if (ck.max * 8u < 0x8000u && seg_iters * 8 <= kPcSegMax) seg_iters *= 8;
             else if (ck.max * 2u < 0x8000u && seg_iters * 2 <= kPcSegMax) seg_iters *= 2;
             else if (ck.max >= 0x8000u && seg_iters > 4) seg_iters /= 2;
+            if (seg_end == F && v_begin + (uint64_t)F * kIterVecs == n_full) straddle_counted = true;
         } else {
             // a counter wrapped: the segment is void.  Restore, and recount it with sweeps
 #pragma unroll
@@ -824,19 +830,11 @@ __global__ __launch_bounds__(kPcThreads) void k_pair_count_u8_fast(const uint8_t
     __syncthreads();
     PC_STAMP();
     pc_flush(hist, bp);
-    // ragged tail: pairs starting at byte 16*n_full - 1 .. n-2
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    // ragged tail: pairs starting at byte 16*n_full - 1 .. n-2, by the workgroup whose range holds the last full vector
+    // (it knows whether its fast iterations counted the straddling pair; no full vector at all: workgroup 0)
+    const bool ends_here = n_full == 0 ? blockIdx.x == 0 : (v_begin < n_full && v_end == n_full);
+    if (ends_here && threadIdx.x == 0) {
         uint64_t i = n_full * 16;
-        // The pair straddling into the tail, (16 n_full - 1, 16 n_full).  The generic loop counts the pairs INSIDE the
-        // full vectors and leaves it to this code; a fast iteration counts every pair that starts in its blocks, so when
-        // the fast iterations of the workgroup that holds the last vector reach n_full it has been counted already.
-        bool straddle_counted = false;
-        if (n_full > 0) {
-            const uint64_t vb = per * ((n_full - 1) / per);          // that workgroup's first vector
-            uint64_t f = (n_full - vb) / kIterVecs;
-            while (f > 0 && (vb + f * kIterVecs) * 16 + 4 > n) --f;
-            straddle_counted = f > 0 && vb + f * kIterVecs == n_full;
-        }
         if (i > 0 && !straddle_counted) --i;
         if (n_full * 16 == n) i = n;         // no tail at all
         for (; i + 1 < n; ++i) atomicAdd(&bp[((uint32_t)text[i] << 8) | text[i + 1]], 1u);

@@ -72,6 +72,26 @@ def test_pair_count_lengths_around_block_edges(tr):
         if not np.array_equal(tr.pair_count_u8(), want):
             bad.append(n)
     assert not bad, bad[:20]
+    # one byte repeated, and nearly so: every segment of the fast loop wraps a 16-bit counter, is restored and recounted by the
+    # generic loop -- which leaves the pair that straddles into the tail to the tail code
+    skew = np.full(len(base), 97, dtype=np.uint8)
+    skew[::4099] = 98
+    for n in sorted(sizes)[::5]:
+        for data in (np.full(n, 97, dtype=np.uint8), skew[:n]):
+            tr.load_corpus(data)
+            want = np.bincount((data[:-1].astype(np.uint32) << 8) | data[1:], minlength=65536).astype(np.uint32)
+            if not np.array_equal(tr.pair_count_u8(), want):
+                bad.append(("skewed", n))
+    assert not bad, bad[:20]
+    # (long enough for a workgroup's counter to wrap inside one segment: 256 workgroups x 4 iterations of 32 KiB)
+    for d in (0, 3, 4, 9, 15, 16, 32768 + 7):
+        n = (32 << 20) + d
+        data = np.full(n, 97, dtype=np.uint8)
+        tr.load_corpus(data)
+        got = tr.pair_count_u8()
+        if got[(97 << 8) | 97] != n - 1 or int(got.sum()) != n - 1:
+            bad.append(("one byte", n, int(got[(97 << 8) | 97])))
+    assert not bad, bad[:20]
     # the same lengths cut into chunks (the masked scan): a pair whose first byte ends a chunk does not count
     for n in sorted(sizes)[::7]:
         data = base[:n]
