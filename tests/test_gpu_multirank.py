@@ -328,3 +328,38 @@ def test_rccl_single_rank_communicator():
         assert t.train_steps(80) == 80
         m, c = t.train_result()
     assert m.tolist() == want_m.tolist() and c.tolist() == want_c.tolist()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MBPE_FUZZ_SHARDED_MEDIUM", "2"))))
+def test_fuzz_sharded_medium(seed):
+    """Shards of thousands of tiles (1-5 MiB over 2-4 ranks): the pair-count scan's whole iterations per shard, batches of
+    hundreds of pairs and the rows they exchange, compactions per rank, matches and runs across the cuts."""
+    rng = np.random.default_rng(52000 + seed)
+    n = int(rng.integers(1 << 20, 5 << 20))
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        data = rng.integers(0, int(rng.choice([3, 7, 20, 256])), size=n, dtype=np.uint8)
+    elif kind == 1:
+        text = read_data("shakespeare.txt")
+        s0 = int(rng.integers(0, len(text) - 300000))
+        ln = int(rng.integers(1000, 300000))
+        data = np.frombuffer((text[s0:s0 + ln] * (n // ln + 1))[:n], dtype=np.uint8).copy()
+    elif kind == 2:
+        vals = rng.integers(97, 103, size=max(n // 20, 1), dtype=np.uint8)
+        data = np.repeat(vals, rng.integers(1, 40, size=len(vals)))[:n]
+    else:
+        data = O.splitmix64_bytes(int(rng.integers(1, 1 << 30)), n)
+    R = int(rng.integers(2, 5))
+    chunk_off = None
+    if rng.integers(0, 3) == 0:
+        inner = np.unique(rng.integers(1, len(data), size=len(data) // int(rng.integers(4, 4000))))
+        chunk_off = np.concatenate([[0], inner, [len(data)]]).astype(np.uint64)
+        cuts = sorted(set(int(x) for x in rng.choice(inner, size=R - 1, replace=False)))
+        # (a chunk that starts with NUL and goes on like a number is ONE inert token in the reference, Tokenizer.h:86-93,
+        #  and inert bytes here: same merges, another stream listing -- tests/test_gpu_fuzz.py; not what this test is about)
+        data = np.where(data == 0, 1, data).astype(np.uint8)
+    else:
+        # (cuts next to the scan's units now and then: k x 32 KiB + a few bytes per shard)
+        cuts = sorted(set(int(x) // 32768 * 32768 + int(rng.integers(0, 20)) if rng.integers(0, 2) else int(x)
+                          for x in rng.integers(32768, len(data), size=R - 1)))
+    _check(np.ascontiguousarray(data).tobytes(), cuts, 256 + int(rng.integers(40, 400)), chunk_off)
