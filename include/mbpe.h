@@ -283,6 +283,11 @@ MBPE_API int mbpe_compact(mbpe_ctx *ctx);
  *                   kernels that sequence needs (one event wait per sequence, ~12 launches instead of ~27), 0 = it
  *                   enqueues whole groups of sequences with every kernel variant and the device decides which work;
  *                   -1 (default): 1 for streams of up to 32 Mi slots on one rank, 0 otherwise.  Same results.
+ *   "pair_cells"    a match whose two neighbours are raw bytes costs the stream pass one atomic on a byte x byte cell block
+ *                   of its pair (65,536 u32 per pair of the largest batch: 1 GiB at the default "max_batch"), folded into
+ *                   the pair's delta rows right behind the pass, instead of two atomics on the rows: 1 / 0, -1 (default) =
+ *                   for streams of 64 Mi slots and more, where the passes of thousands of byte pairs are bound by their
+ *                   atomics; read by mbpe_train_begin.  Same results.
  *   "wide_from"     tests: hand over to the 32-bit continuation after this many merges whatever the vocabulary
  *                   (-1, the default: where the 16-bit slot format ends); read by mbpe_train_begin
  */
