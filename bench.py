@@ -451,16 +451,18 @@ def main():
                             and checks["merges_complete"] and same
                             and all(checks.get("argmax_at_checkpoints", [True])))
 
-    # ---- pair-count scan (the north star's graded kernel), timed last: an idle chip needs ~25 launches of this
+    # ---- pair-count scan (the north star's graded kernel), timed last: an idle chip needs tens of launches of this
     # kernel (some tens of milliseconds of work) to reach its sustained clock -- launch times fall by a fifth
-    # meanwhile; the checks before this point keep it busy with other kernels, and the first ten launches after them
-    # still run 3-4 % slower than the next twenty.  25 launches of warm-up, then 30 launches in
+    # meanwhile; the checks before this point keep it busy with other kernels, and on some boxes the times are still
+    # falling after 25 launches (group means 1.07 / 1.05 / 1.02 / 1.00 / 0.985 and then 0.985 / 0.977 / 0.975 ms:
+    # profiles/README.md).  60 launches of warm-up, whose group means are reported too, then 30 launches in
     # three groups of ten back to back; every dispatch carries its own start / stop events (hipExtLaunchKernelGGL),
     # so avg_launch_ms is the mean KERNEL duration -- no gap between launches, no marker -- which is what rocprofv3
     # reports per dispatch.  (ms_bracket: the same launches between one pair of stream events per group, gaps included.)
     scan_ms, scan_bracket = [], []
     tr.set_option("pc_repeat", 5)
-    for _ in range(5):                       # 25 launches of warm-up in five groups (their means are reported too)
+    n_warm_groups = 12
+    for _ in range(n_warm_groups):           # 60 launches of warm-up in groups of five (their means are reported too)
         tr.pair_count_u8(want_table=False)
         scan_ms.append(tr.stats()["ms_pair_count_kernel"])
     tr.set_option("pc_repeat", 10)
@@ -470,7 +472,7 @@ def main():
         scan_ms.append(st["ms_pair_count_kernel"])
         scan_bracket.append(st["ms_pair_count"])
     tr.set_option("pc_repeat", 1)
-    scan_ms_avg = sum(scan_ms[5:]) / 3.0
+    scan_ms_avg = sum(scan_ms[n_warm_groups:]) / 3.0
     scan_gbs = (hi - lo) / (scan_ms_avg * 1e-3) / 1e9 if scan_ms_avg > 0 else 0.0
 
     if rank == 0:
@@ -541,12 +543,13 @@ def main():
                 "traffic": pmc_traffic("k_pair_count_u8_fast", args.config, total_bytes, vocab, world),
                 "algorithmic_bytes_per_launch": hi - lo,
                 "avg_launch_ms": scan_ms_avg,
-                "avg_launch_ms_is": "mean kernel duration of launches 26-55 of 55 (three groups of ten launches back to back), "
-                                    "each dispatch timed by its own start/stop events (hipExtLaunchKernelGGL), after 25 "
+                "avg_launch_ms_is": "mean kernel duration of launches 61-90 of 90 (three groups of ten launches back to back), "
+                                    "each dispatch timed by its own start/stop events (hipExtLaunchKernelGGL), after 60 "
                                     "warm-up launches (the kernel's sustained clock: an idle or differently loaded chip "
-                                    "takes ~25 launches of it to get there), taken after the training runs of this process",
+                                    "takes tens of launches of it to get there; launch_ms_all shows the approach), taken "
+                                    "after the training runs of this process",
                 "launch_ms_all": [round(x, 4) for x in scan_ms],
-                "launch_ms_all_is": "mean kernel duration of five warm-up groups of five launches, then of each timed group of ten",
+                "launch_ms_all_is": "mean kernel duration of the twelve warm-up groups of five launches, then of each timed group of ten",
                 "ms_bracket": [round(x, 4) for x in scan_bracket],
                 "ms_bracket_is": "the same groups of ten between ONE pair of stream events, per launch: gaps between "
                                  "launches included",
